@@ -1,0 +1,276 @@
+// BatchNorm1d over the rows of a voxel/point feature matrix, fused with the optional
+// residual add and ReLU that follow it in every SPVCNN block
+// (models/spvcnn.py:30-31,71-79,100-102,164-180).  HBM-bound: x is read twice in the
+// forward (statistics, apply) and the output written once; statistics accumulate in
+// float64 so mean/var do not depend on how rows are split over workgroups.
+#include "ftx_common.h"
+
+using namespace ftx;
+
+constexpr int BN_MAX_BLOCKS = 1024;
+constexpr int BN_ROWS_PER_BLOCK = 128;
+
+static int bn_blocks(int64_t n) {
+  int64_t b = ceil_div(n, BN_ROWS_PER_BLOCK);
+  if (b > BN_MAX_BLOCKS) b = BN_MAX_BLOCKS;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+extern "C" size_t ftx_bn_workspace_bytes(int64_t n, int32_t c) {
+  if (c <= 0) return 256;
+  return sizeof(double) * (size_t)bn_blocks(n) * 2 * c + sizeof(double) * 2 * c;
+}
+
+// Per-block partial column sums of two quantities (q0, q1) produced by `Op` for each element.
+//   forward:  q0 = x,        q1 = x*x
+//   backward: q0 = dy,       q1 = dy * xhat      (dy masked by y>0 when relu)
+struct FwdOp {
+  __device__ static void eval(float x, float, float, float, float, int, double &q0, double &q1) {
+    q0 = (double)x;
+    q1 = (double)x * (double)x;
+  }
+};
+struct BwdOp {
+  __device__ static void eval(float x, float gy, float y, float mean, float invstd, int relu, double &q0, double &q1) {
+    float dy = (relu && !(y > 0.f)) ? 0.f : gy;
+    q0 = (double)dy;
+    q1 = (double)dy * (double)((x - mean) * invstd);
+  }
+};
+
+template <class Op>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict__ x, const float *__restrict__ gy,
+                                                         const float *__restrict__ y, const float *__restrict__ mean,
+                                                         const float *__restrict__ invstd, int relu, int64_t n, int c,
+                                                         double *__restrict__ part) {
+  extern __shared__ double sh[];  // [2][RL][c]
+  const int c4 = c >> 2;
+  const int RL = 256 / c4 > 0 ? 256 / c4 : 1;
+  const int tid = threadIdx.x;
+  const int cg = tid % c4, rl = tid / c4;
+  const int64_t rows_per_block = ceil_div(n, (int64_t)gridDim.x);
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < n) ? r0 + rows_per_block : n;
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  if (rl < RL) {
+    float4 mu = make_float4(0, 0, 0, 0), is = mu;
+    if (mean) {
+      mu = *(const float4 *)&mean[cg * 4];
+      is = *(const float4 *)&invstd[cg * 4];
+    }
+    for (int64_t r = r0 + rl; r < r1; r += RL) {
+      float4 xv = *(const float4 *)&x[r * c + cg * 4];
+      float4 gv = make_float4(0, 0, 0, 0), yv = gv;
+      if (gy) gv = *(const float4 *)&gy[r * c + cg * 4];
+      if (y) yv = *(const float4 *)&y[r * c + cg * 4];
+      double a, b;
+      Op::eval(xv.x, gv.x, yv.x, mu.x, is.x, relu, a, b); s0[0] += a; s1[0] += b;
+      Op::eval(xv.y, gv.y, yv.y, mu.y, is.y, relu, a, b); s0[1] += a; s1[1] += b;
+      Op::eval(xv.z, gv.z, yv.z, mu.z, is.z, relu, a, b); s0[2] += a; s1[2] += b;
+      Op::eval(xv.w, gv.w, yv.w, mu.w, is.w, relu, a, b); s0[3] += a; s1[3] += b;
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      sh[(0 * RL + rl) * c + cg * 4 + v] = s0[v];
+      sh[(1 * RL + rl) * c + cg * 4 + v] = s1[v];
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < 2 * c; j += 256) {
+    int which = j / c, col = j - which * c;
+    double s = 0;
+    for (int q = 0; q < RL; ++q) s += sh[(which * RL + q) * c + col];
+    part[((int64_t)blockIdx.x * 2 + which) * c + col] = s;
+  }
+}
+
+__global__ void bn_finalize_fwd_kernel(const double *__restrict__ part, int nb, int64_t n, int c, float eps, float momentum,
+                                       float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ save_mean,
+                                       float *__restrict__ save_invstd) {
+  for (int col = blockIdx.x * blockDim.x + threadIdx.x; col < c; col += gridDim.x * blockDim.x) {
+    double s = 0, ss = 0;
+    for (int b = 0; b < nb; ++b) {
+      s += part[((int64_t)b * 2 + 0) * c + col];
+      ss += part[((int64_t)b * 2 + 1) * c + col];
+    }
+    double mean = s / (double)n;
+    double var = ss / (double)n - mean * mean;
+    if (var < 0) var = 0;
+    save_mean[col] = (float)mean;
+    save_invstd[col] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) running_mean[col] = (1.f - momentum) * running_mean[col] + momentum * (float)mean;
+    if (running_var) {
+      double unbiased = n > 1 ? var * (double)n / (double)(n - 1) : var;
+      running_var[col] = (1.f - momentum) * running_var[col] + momentum * (float)unbiased;
+    }
+  }
+}
+
+__global__ void bn_apply_fwd_kernel(const float *__restrict__ x, const float *__restrict__ res, const float *__restrict__ gamma,
+                                    const float *__restrict__ beta, const float *__restrict__ mean, const float *__restrict__ invstd,
+                                    int64_t n, int c, int relu, float *__restrict__ y) {
+  const int c4 = c >> 2;
+  const int64_t total = n * c4;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    int col = (int)(e % c4) * 4;
+    float4 xv = *(const float4 *)&x[e * 4];
+    float4 mu = *(const float4 *)&mean[col], is = *(const float4 *)&invstd[col];
+    float4 g = *(const float4 *)&gamma[col], b = *(const float4 *)&beta[col];
+    float4 o;
+    o.x = (xv.x - mu.x) * is.x * g.x + b.x;
+    o.y = (xv.y - mu.y) * is.y * g.y + b.y;
+    o.z = (xv.z - mu.z) * is.z * g.z + b.z;
+    o.w = (xv.w - mu.w) * is.w * g.w + b.w;
+    if (res) {
+      float4 rv = *(const float4 *)&res[e * 4];
+      o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+    }
+    if (relu) {
+      o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
+      o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+    }
+    *(float4 *)&y[e * 4] = o;
+  }
+}
+
+static int bn_check(const char *who, int64_t n, int c) {
+  FTX_REQUIRE(n >= 0, "%s: n < 0", who);
+  FTX_REQUIRE(c >= 4 && c % 4 == 0 && c <= 1024, "%s: c must be a multiple of 4 in [4,1024] (got %d)", who, c);
+  return FTX_OK;
+}
+
+static size_t bn_partial_lds(int c) {
+  int c4 = c / 4;
+  int RL = 256 / c4 > 0 ? 256 / c4 : 1;
+  return sizeof(double) * 2 * RL * c;
+}
+
+extern "C" int ftx_bn_train_fwd(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean,
+                                float *running_var, float momentum, float eps, int64_t n, int32_t c, int32_t relu, float *y,
+                                float *save_mean, float *save_invstd, void *workspace, size_t workspace_bytes, void *stream) {
+  int rc = bn_check("ftx_bn_train_fwd", n, c);
+  if (rc != FTX_OK) return rc;
+  FTX_REQUIRE(n >= 1, "ftx_bn_train_fwd: needs at least one row");
+  FTX_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && workspace, "ftx_bn_train_fwd: null pointer");
+  FTX_REQUIRE(c <= 512, "ftx_bn_train_fwd: c > 512 unsupported");
+  if (workspace_bytes < ftx_bn_workspace_bytes(n, c)) {
+    set_error("ftx_bn_train_fwd: workspace %zu < required %zu", workspace_bytes, ftx_bn_workspace_bytes(n, c));
+    return FTX_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = bn_blocks(n);
+  double *part = (double *)workspace;
+  bn_partial_kernel<FwdOp><<<nb, 256, bn_partial_lds(c), st>>>(x, nullptr, nullptr, nullptr, nullptr, 0, n, c, part);
+  bn_finalize_fwd_kernel<<<ceil_div(c, 256), 256, 0, st>>>(part, nb, n, c, eps, momentum, running_mean, running_var, save_mean, save_invstd);
+  bn_apply_fwd_kernel<<<grid_for(n * (c / 4), 256), 256, 0, st>>>(x, residual, gamma, beta, save_mean, save_invstd, n, c, relu, y);
+  return check_launch("ftx_bn_train_fwd");
+}
+
+__global__ void bn_apply_eval_kernel(const float *__restrict__ x, const float *__restrict__ res, const float *__restrict__ gamma,
+                                     const float *__restrict__ beta, const float *__restrict__ rm, const float *__restrict__ rv, float eps,
+                                     int64_t n, int c, int relu, float *__restrict__ y) {
+  const int c4 = c >> 2;
+  const int64_t total = n * c4;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    int col = (int)(e % c4) * 4;
+    float4 xv = *(const float4 *)&x[e * 4];
+    float o[4] = {xv.x, xv.y, xv.z, xv.w};
+    float rr[4] = {0, 0, 0, 0};
+    if (res) {
+      float4 t = *(const float4 *)&res[e * 4];
+      rr[0] = t.x; rr[1] = t.y; rr[2] = t.z; rr[3] = t.w;
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      float is = (float)(1.0 / sqrt((double)rv[col + v] + (double)eps));
+      float t = (o[v] - rm[col + v]) * is * gamma[col + v] + beta[col + v] + rr[v];
+      o[v] = (relu && !(t > 0.f)) ? 0.f : t;
+    }
+    *(float4 *)&y[e * 4] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+extern "C" int ftx_bn_eval_fwd(const float *x, const float *residual, const float *gamma, const float *beta, const float *running_mean,
+                               const float *running_var, float eps, int64_t n, int32_t c, int32_t relu, float *y, void *stream) {
+  int rc = bn_check("ftx_bn_eval_fwd", n, c);
+  if (rc != FTX_OK) return rc;
+  if (n == 0) return FTX_OK;
+  FTX_REQUIRE(x && gamma && beta && running_mean && running_var && y, "ftx_bn_eval_fwd: null pointer");
+  bn_apply_eval_kernel<<<grid_for(n * (c / 4), 256), 256, 0, (hipStream_t)stream>>>(x, residual, gamma, beta, running_mean, running_var, eps,
+                                                                                     n, c, relu, y);
+  return check_launch("ftx_bn_eval_fwd");
+}
+
+__global__ void bn_finalize_bwd_kernel(const double *__restrict__ part, int nb, int c, double *__restrict__ sums,
+                                       float *__restrict__ grad_gamma, float *__restrict__ grad_beta) {
+  for (int col = blockIdx.x * blockDim.x + threadIdx.x; col < c; col += gridDim.x * blockDim.x) {
+    double s = 0, ss = 0;
+    for (int b = 0; b < nb; ++b) {
+      s += part[((int64_t)b * 2 + 0) * c + col];
+      ss += part[((int64_t)b * 2 + 1) * c + col];
+    }
+    sums[col] = s;
+    sums[c + col] = ss;
+    if (grad_beta) grad_beta[col] = (float)s;
+    if (grad_gamma) grad_gamma[col] = (float)ss;
+  }
+}
+
+__global__ void bn_apply_bwd_kernel(const float *__restrict__ gy, const float *__restrict__ x, const float *__restrict__ y,
+                                    const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ invstd,
+                                    const double *__restrict__ sums, int64_t n, int c, int relu, float *__restrict__ gx,
+                                    float *__restrict__ gres) {
+  const int c4 = c >> 2;
+  const int64_t total = n * c4;
+  const float inv_n = 1.f / (float)n;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    int col = (int)(e % c4) * 4;
+    float4 g4 = *(const float4 *)&gy[e * 4];
+    float4 x4 = *(const float4 *)&x[e * 4];
+    float dy[4] = {g4.x, g4.y, g4.z, g4.w};
+    float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+    if (relu) {
+      float4 y4 = *(const float4 *)&y[e * 4];
+      float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (!(yv[v] > 0.f)) dy[v] = 0.f;
+    }
+    float o[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      float is = invstd[col + v];
+      float xhat = (xv[v] - mean[col + v]) * is;
+      float sdy = (float)sums[col + v] * inv_n;
+      float sdyx = (float)sums[c + col + v] * inv_n;
+      o[v] = gamma[col + v] * is * (dy[v] - sdy - xhat * sdyx);
+    }
+    *(float4 *)&gx[e * 4] = make_float4(o[0], o[1], o[2], o[3]);
+    if (gres) *(float4 *)&gres[e * 4] = make_float4(dy[0], dy[1], dy[2], dy[3]);
+  }
+}
+
+extern "C" int ftx_bn_train_bwd(const float *grad_y, const float *x, const float *y, const float *gamma, const float *save_mean,
+                                const float *save_invstd, int64_t n, int32_t c, int32_t relu, float *grad_x, float *grad_residual,
+                                float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream) {
+  int rc = bn_check("ftx_bn_train_bwd", n, c);
+  if (rc != FTX_OK) return rc;
+  FTX_REQUIRE(n >= 1, "ftx_bn_train_bwd: needs at least one row");
+  FTX_REQUIRE(grad_y && x && gamma && save_mean && save_invstd && grad_x && workspace, "ftx_bn_train_bwd: null pointer");
+  FTX_REQUIRE(!relu || y, "ftx_bn_train_bwd: relu needs the forward output y");
+  FTX_REQUIRE(c <= 512, "ftx_bn_train_bwd: c > 512 unsupported");
+  if (workspace_bytes < ftx_bn_workspace_bytes(n, c)) {
+    set_error("ftx_bn_train_bwd: workspace %zu < required %zu", workspace_bytes, ftx_bn_workspace_bytes(n, c));
+    return FTX_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = bn_blocks(n);
+  double *part = (double *)workspace;
+  double *sums = part + (size_t)nb * 2 * c;
+  bn_partial_kernel<BwdOp><<<nb, 256, bn_partial_lds(c), st>>>(x, grad_y, relu ? y : nullptr, save_mean, save_invstd, relu, n, c, part);
+  bn_finalize_bwd_kernel<<<ceil_div(c, 256), 256, 0, st>>>(part, nb, c, sums, grad_gamma, grad_beta);
+  bn_apply_bwd_kernel<<<grid_for(n * (c / 4), 256), 256, 0, st>>>(grad_y, x, y, gamma, save_mean, save_invstd, sums, n, c, relu, grad_x,
+                                                                   grad_residual);
+  return check_launch("ftx_bn_train_bwd");
+}

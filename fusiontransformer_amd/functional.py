@@ -1,0 +1,427 @@
+"""Host-side operator surface over libftx: the torchsparse `spf.*` functions the
+reference calls (models/utils.py:19-27,44-58,71-99), the kernel-map builder and
+sparse convolution hidden inside `spnn.Conv3d` (models/spvcnn.py:26-30), the
+fused BatchNorm(+residual)(+ReLU), and the fused nearest-upsample + lift gather
+of `Net2DBillinear.get_img_feats` (models/image_models_billinear.py:113-124).
+
+Same names and argument meaning as the reference's imports; tensors live on
+the GPU, index tensors are int32 (torchsparse returns int64 and immediately
+`.int()`s them, utils.py:22,51)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr, req, stream
+
+I32, I64, F32 = torch.int32, torch.int64, torch.float32
+
+
+def _empty(shape, dtype, like):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+# ---------------------------------------------------------------- integer side
+def sphash(coords: torch.Tensor, offsets: torch.Tensor | None = None) -> torch.Tensor:
+    """spf.sphash: (N,4) int32 -> (N,) int64, or with (K,3) offsets -> (K,N)."""
+    L = _lib.load()
+    req(coords, I32, "sphash coords", 2)
+    if coords.shape[1] != 4:
+        raise ValueError("sphash: coords must be (N,4)")
+    n = coords.shape[0]
+    if offsets is None:
+        out = _empty((n,), I64, coords)
+        check(L.ftx_hash(ptr(coords), n, ptr(out), stream()), "ftx_hash")
+        return out
+    req(offsets, I32, "sphash offsets", 2)
+    k = offsets.shape[0]
+    out = _empty((k, n), I64, coords)
+    check(L.ftx_hash_kernel(ptr(coords), n, ptr(offsets), k, ptr(out), stream()), "ftx_hash_kernel")
+    return out
+
+
+def floor_coords(pc: torch.Tensor, stride: int) -> torch.Tensor:
+    """cat([floor(pc[:, :3] / s).int() * s, pc[:, -1].int()]) (models/utils.py:44-48)."""
+    L = _lib.load()
+    req(pc, F32, "floor_coords pc", 2)
+    if pc.shape[1] != 4:
+        raise ValueError("floor_coords: pc must be (N,4)")
+    out = _empty(pc.shape, I32, pc)
+    check(L.ftx_floor_coords(ptr(pc), pc.shape[0], int(stride), ptr(out), stream()), "ftx_floor_coords")
+    return out
+
+
+class HashTable:
+    """Open-addressing table (64-bit keys -> int32 row) resident in HBM."""
+
+    def __init__(self, keys: torch.Tensor):
+        L = _lib.load()
+        req(keys, I64, "HashTable keys", 1)
+        self.n = keys.shape[0]
+        self.capacity = int(L.ftx_hashtable_capacity(self.n))
+        self.keys = _empty((self.capacity,), I64, keys)
+        self.vals = _empty((self.capacity,), I32, keys)
+        check(L.ftx_hashtable_build(ptr(keys), self.n, ptr(self.keys), ptr(self.vals), self.capacity, stream()), "ftx_hashtable_build")
+
+    def query(self, q: torch.Tensor) -> torch.Tensor:
+        L = _lib.load()
+        req(q, I64, "HashTable query")
+        out = _empty(q.shape, I32, q)
+        check(L.ftx_hashtable_query(ptr(q), q.numel(), ptr(self.keys), ptr(self.vals), self.capacity, ptr(out), stream()), "ftx_hashtable_query")
+        return out
+
+
+def sphashquery(hash_query: torch.Tensor, hash_target: torch.Tensor) -> torch.Tensor:
+    """spf.sphashquery: row of each query hash in hash_target, -1 if absent (int32)."""
+    return HashTable(hash_target).query(hash_query)
+
+
+def spcount(idx: torch.Tensor, n: int) -> torch.Tensor:
+    L = _lib.load()
+    req(idx, I32, "spcount idx", 1)
+    out = _empty((int(n),), I32, idx)
+    check(L.ftx_count(ptr(idx), idx.shape[0], ptr(out), int(n), stream()), "ftx_count")
+    return out
+
+
+def unique_sorted(keys: torch.Tensor):
+    """torch.unique(keys) (ascending) plus the row of the first occurrence of each.
+
+    Returns (uniq (n,), first_index (n,), n_unique (1,) int32 ON DEVICE); rows
+    past n_unique are unspecified.  No host sync here."""
+    L = _lib.load()
+    req(keys, I64, "unique_sorted keys", 1)
+    n = keys.shape[0]
+    uniq = _empty((n,), I64, keys)
+    first = _empty((n,), I32, keys)
+    cnt = torch.zeros((1,), dtype=I32, device=keys.device)
+    ws_bytes = int(L.ftx_unique_workspace_bytes(n))
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=keys.device)
+    check(L.ftx_unique_sorted(ptr(keys), n, ptr(uniq), ptr(first), ptr(cnt), ptr(ws), ws_bytes, stream()), "ftx_unique_sorted")
+    return uniq, first, cnt
+
+
+def downsample_coords(coords: torch.Tensor, ratio: int) -> torch.Tensor:
+    L = _lib.load()
+    req(coords, I32, "downsample coords", 2)
+    out = torch.empty_like(coords)
+    check(L.ftx_downsample_coords(ptr(coords), coords.shape[0], int(ratio), ptr(out), stream()), "ftx_downsample_coords")
+    return out
+
+
+def gather_coords(src: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    L = _lib.load()
+    req(src, I32, "gather_coords src", 2)
+    req(index, I32, "gather_coords index", 1)
+    out = _empty((index.shape[0], 4), I32, src)
+    check(L.ftx_gather_coords(ptr(src), ptr(index), index.shape[0], ptr(out), stream()), "ftx_gather_coords")
+    return out
+
+
+def kernel_offsets(kernel_size: int, tensor_stride: int = 1) -> np.ndarray:
+    """torchsparse KernelRegion(kernel_size, tensor_stride).get_kernel_offset():
+    odd kernels enumerate x fastest, even kernels z fastest."""
+    single = (np.arange(-kernel_size // 2 + 1, kernel_size // 2 + 1) * tensor_stride).tolist()
+    if kernel_size % 2 == 1:
+        offs = [[x, y, z] for z in single for y in single for x in single]
+    else:
+        offs = [[x, y, z] for x in single for y in single for z in single]
+    return np.array(offs, dtype=np.int32)
+
+
+def kernel_map_build(out_coords: torch.Tensor, offsets: torch.Tensor, table: HashTable) -> torch.Tensor:
+    """nbr (K, N_out) int32: row of out_coords[o]+offsets[k] among the table's keys, or -1."""
+    L = _lib.load()
+    req(out_coords, I32, "kernel_map out_coords", 2)
+    req(offsets, I32, "kernel_map offsets", 2)
+    n_out, k = out_coords.shape[0], offsets.shape[0]
+    nbr = _empty((k, n_out), I32, out_coords)
+    check(L.ftx_kernel_map_build(ptr(out_coords), n_out, ptr(offsets), k, ptr(table.keys), ptr(table.vals), table.capacity, ptr(nbr), stream()),
+          "ftx_kernel_map_build")
+    return nbr
+
+
+def kernel_map_transpose(nbr: torch.Tensor, n_in: int) -> torch.Tensor:
+    L = _lib.load()
+    req(nbr, I32, "kernel_map_transpose nbr", 2)
+    k, n_out = nbr.shape
+    out = _empty((k, int(n_in)), I32, nbr)
+    check(L.ftx_kernel_map_transpose(ptr(nbr), n_out, int(n_in), k, ptr(out), stream()), "ftx_kernel_map_transpose")
+    return out
+
+
+def calc_ti_weights(pc: torch.Tensor, idx_query: torch.Tensor, scale: int = 1) -> torch.Tensor:
+    """spf.calc_ti_weights, already in the point-major (N,8) layout of utils.py:82-83."""
+    L = _lib.load()
+    req(pc, F32, "calc_ti_weights pc", 2)
+    req(idx_query, I32, "calc_ti_weights idx", 2)
+    n = pc.shape[0]
+    if pc.shape[1] != 4 or idx_query.shape != (n, 8):
+        raise ValueError("calc_ti_weights: pc must be (N,4) and idx (N,8)")
+    w = _empty((n, 8), F32, pc)
+    check(L.ftx_trilinear_weights(ptr(pc), ptr(idx_query), n, int(scale), ptr(w), stream()), "ftx_trilinear_weights")
+    return w
+
+
+# ---------------------------------------------------------------- voxelize / devoxelize
+class _Voxelize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, idx, counts):
+        L = _lib.load()
+        feats = req(feats.contiguous(), F32, "spvoxelize feats", 2)
+        req(idx, I32, "spvoxelize idx", 1)
+        req(counts, I32, "spvoxelize counts", 1)
+        n, c = feats.shape
+        if idx.shape[0] != n:
+            raise ValueError("spvoxelize: idx length != rows of feats")
+        m = counts.shape[0]
+        out = _empty((m, c), F32, feats)
+        check(L.ftx_voxelize_fwd(ptr(feats), ptr(idx), ptr(counts), n, c, m, ptr(out), stream()), "ftx_voxelize_fwd")
+        ctx.save_for_backward(idx, counts)
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        L = _lib.load()
+        idx, counts = ctx.saved_tensors
+        grad_out = req(grad_out.contiguous(), F32, "spvoxelize grad", 2)
+        m, c = grad_out.shape
+        gf = _empty((ctx.n, c), F32, grad_out)
+        check(L.ftx_voxelize_bwd(ptr(grad_out), ptr(idx), ptr(counts), ctx.n, c, m, ptr(gf), stream()), "ftx_voxelize_bwd")
+        return gf, None, None
+
+
+def spvoxelize(feats, idx, counts):
+    """spf.spvoxelize (scatter-mean of point rows into voxel rows)."""
+    return _Voxelize.apply(feats, idx, counts)
+
+
+class _Devoxelize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, idx, weights):
+        L = _lib.load()
+        feats = req(feats.contiguous(), F32, "spdevoxelize feats", 2)
+        req(idx, I32, "spdevoxelize idx", 2)
+        req(weights, F32, "spdevoxelize weights", 2)
+        m, c = feats.shape
+        n = idx.shape[0]
+        if idx.shape != (n, 8) or weights.shape != (n, 8):
+            raise ValueError("spdevoxelize: idx and weights must be (N,8)")
+        out = _empty((n, c), F32, feats)
+        check(L.ftx_devoxelize_fwd(ptr(feats), ptr(idx), ptr(weights), n, c, m, ptr(out), stream()), "ftx_devoxelize_fwd")
+        ctx.save_for_backward(idx, weights)
+        ctx.m = m
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        L = _lib.load()
+        idx, weights = ctx.saved_tensors
+        grad_out = req(grad_out.contiguous(), F32, "spdevoxelize grad", 2)
+        n, c = grad_out.shape
+        gf = _empty((ctx.m, c), F32, grad_out)
+        check(L.ftx_devoxelize_bwd(ptr(grad_out), ptr(idx), ptr(weights), n, c, ctx.m, ptr(gf), stream()), "ftx_devoxelize_bwd")
+        return gf, None, None
+
+
+def spdevoxelize(feats, idx, weights):
+    """spf.spdevoxelize (8-corner weighted gather of voxel rows onto points)."""
+    return _Devoxelize.apply(feats, idx, weights)
+
+
+# ---------------------------------------------------------------- sparse convolution
+def _spconv_gemm(A, W, tbl, n_out, co, w_transposed):
+    L = _lib.load()
+    rows_a, ca = A.shape
+    kvol = tbl.shape[0]
+    out = _empty((n_out, co), F32, A)
+    check(L.ftx_spconv_gemm(ptr(A), rows_a, ptr(W), ptr(tbl), n_out, ca, co, kvol, int(w_transposed), ptr(out), stream()), "ftx_spconv_gemm")
+    return out
+
+
+def _spconv_wgrad(A, G, tbl, kvol):
+    L = _lib.load()
+    rows_a, ca = A.shape
+    n_rows, cg = G.shape
+    dW = _empty((kvol, ca, cg), F32, A)
+    ws_bytes = int(L.ftx_spconv_wgrad_workspace_bytes(n_rows, ca, cg, kvol))
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=A.device)
+    check(L.ftx_spconv_wgrad(ptr(A), rows_a, ptr(G), ptr(tbl), n_rows, ca, cg, kvol, ptr(dW), ptr(ws), ws_bytes, stream()), "ftx_spconv_wgrad")
+    return dW
+
+
+class _SparseConv(torch.autograd.Function):
+    """out[r] = sum_k feats[tbl_fwd[k,r]] @ kernel[k].
+
+    tbl_fwd (K, n_out) indexes rows of `feats`; tbl_bwd (K, n_in) is its transpose
+    (rows of grad_out).  For a strided conv tbl_fwd = nbr, tbl_bwd = nbr_t; the
+    transposed conv passes them the other way round (models/spvcnn.py:42-46)."""
+
+    @staticmethod
+    def forward(ctx, feats, kernel, tbl_fwd, tbl_bwd):
+        feats = req(feats.contiguous(), F32, "conv3d feats", 2)
+        kernel = req(kernel.contiguous(), F32, "conv3d kernel", 3)
+        req(tbl_fwd, I32, "conv3d tbl_fwd", 2)
+        req(tbl_bwd, I32, "conv3d tbl_bwd", 2)
+        kvol, ca, co = kernel.shape
+        if feats.shape[1] != ca or tbl_fwd.shape[0] != kvol or tbl_bwd.shape[0] != kvol:
+            raise ValueError(f"conv3d: shape mismatch feats {tuple(feats.shape)} kernel {tuple(kernel.shape)} tbl {tuple(tbl_fwd.shape)}")
+        if tbl_bwd.shape[1] != feats.shape[0]:
+            raise ValueError("conv3d: transposed table does not match the input rows")
+        out = _spconv_gemm(feats, kernel, tbl_fwd, tbl_fwd.shape[1], co, 0)
+        ctx.save_for_backward(feats, kernel, tbl_fwd, tbl_bwd)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        feats, kernel, tbl_fwd, tbl_bwd = ctx.saved_tensors
+        grad_out = req(grad_out.contiguous(), F32, "conv3d grad", 2)
+        kvol, ca, co = kernel.shape
+        g_feats = g_kernel = None
+        if ctx.needs_input_grad[0]:
+            g_feats = _spconv_gemm(grad_out, kernel, tbl_bwd, feats.shape[0], ca, 1)
+        if ctx.needs_input_grad[1]:
+            g_kernel = _spconv_wgrad(feats, grad_out, tbl_fwd, kvol)
+        return g_feats, g_kernel, None, None
+
+
+def sparse_conv(feats, kernel, tbl_fwd, tbl_bwd):
+    return _SparseConv.apply(feats, kernel, tbl_fwd, tbl_bwd)
+
+
+# ---------------------------------------------------------------- BatchNorm (+residual)(+ReLU)
+class _BatchNormTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu):
+        L = _lib.load()
+        x = req(x.contiguous(), F32, "bn x", 2)
+        n, c = x.shape
+        if residual is not None:
+            residual = req(residual.contiguous(), F32, "bn residual", 2)
+            if residual.shape != x.shape:
+                raise ValueError("bn: residual shape mismatch")
+        for t, nm in ((gamma, "gamma"), (beta, "beta")):
+            req(t, F32, "bn " + nm, 1)
+            if t.shape[0] != c:
+                raise ValueError("bn: parameter length != channels")
+        y = torch.empty_like(x)
+        mean = _empty((c,), F32, x)
+        invstd = _empty((c,), F32, x)
+        ws_bytes = int(L.ftx_bn_workspace_bytes(n, c))
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+        check(L.ftx_bn_train_fwd(ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps),
+                                 n, c, int(relu), ptr(y), ptr(mean), ptr(invstd), ptr(ws), ws_bytes, stream()), "ftx_bn_train_fwd")
+        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        ctx.relu = int(relu)
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.load()
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        gy = req(gy.contiguous(), F32, "bn grad", 2)
+        n, c = x.shape
+        gx = torch.empty_like(x)
+        gres = torch.empty_like(x) if ctx.has_res else None
+        ggamma = _empty((c,), F32, x)
+        gbeta = _empty((c,), F32, x)
+        ws_bytes = int(L.ftx_bn_workspace_bytes(n, c))
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+        check(L.ftx_bn_train_bwd(ptr(gy), ptr(x), ptr(y), ptr(gamma), ptr(mean), ptr(invstd), n, c, ctx.relu, ptr(gx), ptr(gres), ptr(ggamma),
+                                 ptr(gbeta), ptr(ws), ws_bytes, stream()), "ftx_bn_train_bwd")
+        return gx, gres, ggamma, gbeta, None, None, None, None, None
+
+
+class _BatchNormEval(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, eps, relu):
+        L = _lib.load()
+        x = req(x.contiguous(), F32, "bn x", 2)
+        n, c = x.shape
+        if residual is not None:
+            residual = req(residual.contiguous(), F32, "bn residual", 2)
+        y = torch.empty_like(x)
+        check(L.ftx_bn_eval_fwd(ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps), n, c, int(relu),
+                                ptr(y), stream()), "ftx_bn_eval_fwd")
+        ctx.save_for_backward(y, gamma, running_var)
+        ctx.eps, ctx.relu, ctx.has_res = float(eps), int(relu), residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        # Eval-mode gradients are elementwise; torch device ops (no library call needed).
+        y, gamma, running_var = ctx.saved_tensors
+        dy = gy * (y > 0) if ctx.relu else gy
+        scale = gamma * torch.rsqrt(running_var + ctx.eps)
+        gx = dy * scale
+        return gx, (dy if ctx.has_res else None), None, None, None, None, None, None
+
+
+def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, residual=None, relu=False):
+    """y = relu?(BN(x) (+ residual)) over the rows of x (N,C)."""
+    if training:
+        return _BatchNormTrain.apply(x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu)
+    return _BatchNormEval.apply(x, residual, gamma, beta, running_mean, running_var, eps, relu)
+
+
+# ---------------------------------------------------------------- 2D -> 3D lift, nearest resample
+class _LiftGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, grid, img_idx, point_batch, H, W):
+        L = _lib.load()
+        grid = req(grid.contiguous(), F32, "lift grid", 4)
+        req(img_idx, I64, "lift img_idx", 2)
+        req(point_batch, I32, "lift point_batch", 1)
+        b, gh, gw, c = grid.shape
+        n = img_idx.shape[0]
+        if img_idx.shape != (n, 2) or point_batch.shape[0] != n:
+            raise ValueError("lift_gather: img_idx must be (N,2), point_batch (N,)")
+        out = _empty((n, c), F32, grid)
+        check(L.ftx_lift_gather_fwd(ptr(grid), ptr(img_idx), ptr(point_batch), n, b, gh, gw, c, int(H), int(W), ptr(out), stream()), "ftx_lift_gather_fwd")
+        ctx.save_for_backward(img_idx, point_batch)
+        ctx.dims = (b, gh, gw, c, int(H), int(W))
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        L = _lib.load()
+        img_idx, point_batch = ctx.saved_tensors
+        b, gh, gw, c, H, W = ctx.dims
+        go = req(go.contiguous(), F32, "lift grad", 2)
+        gg = _empty((b, gh, gw, c), F32, go)
+        check(L.ftx_lift_gather_bwd(ptr(go), ptr(img_idx), ptr(point_batch), go.shape[0], b, gh, gw, c, H, W, ptr(gg), stream()), "ftx_lift_gather_bwd")
+        return gg, None, None, None, None
+
+
+def lift_gather(grid, img_idx, point_batch, H, W):
+    """Per-point rows of nearest-upsample(grid -> (H,W)) without materialising the map."""
+    return _LiftGather.apply(grid, img_idx, point_batch, H, W)
+
+
+class _ResampleNearest(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, oh, ow):
+        L = _lib.load()
+        x = req(x.contiguous(), F32, "resample x", 4)
+        b, c, ih, iw = x.shape
+        out = _empty((b, c, int(oh), int(ow)), F32, x)
+        check(L.ftx_resample_nearest_fwd(ptr(x), b, c, ih, iw, int(oh), int(ow), ptr(out), stream()), "ftx_resample_nearest_fwd")
+        ctx.dims = (b, c, ih, iw, int(oh), int(ow))
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        L = _lib.load()
+        b, c, ih, iw, oh, ow = ctx.dims
+        go = req(go.contiguous(), F32, "resample grad", 4)
+        gi = _empty((b, c, ih, iw), F32, go)
+        check(L.ftx_resample_nearest_bwd(ptr(go), b, c, ih, iw, oh, ow, ptr(gi), stream()), "ftx_resample_nearest_bwd")
+        return gi, None, None
+
+
+def resample_nearest(x, size):
+    """nn.Upsample(size) (nearest) on NCHW."""
+    return _ResampleNearest.apply(x, size[0], size[1])

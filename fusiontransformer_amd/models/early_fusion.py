@@ -1,0 +1,35 @@
+"""EarlyFusionTransformer: mirror of FusionTransformer/models/early_fusion.py:9-114."""
+from __future__ import annotations
+
+import torch.nn as nn
+
+from ._fusion_common import fused_outputs, heads, image_branch, lidar_preds
+from .spvcnn import SPVCNN, BatchNorm, _linear_bn_relu
+
+
+class Net3DSeg(SPVCNN):
+    def __init__(self, num_classes, dual_head, backbone_3d_kwargs=dict()):
+        super(Net3DSeg, self).__init__(**backbone_3d_kwargs)
+        self.early_fusion_transform = nn.Sequential(nn.Linear(96, 32), BatchNorm(32), nn.ReLU(True))
+        heads(self, self.cs[-1], num_classes, dual_head)
+
+    def backbone_forward_pass(self, x, img_early_feats):
+        # z0.F = z0.F + early_fusion_transform(img_early_feats)  (early_fusion.py:39)
+        return self._backbone(x, fuse_early=_linear_bn_relu(self.early_fusion_transform, img_early_feats))
+
+    def forward(self, x, img_early_feats):
+        return lidar_preds(self, self.backbone_forward_pass(x, img_early_feats))
+
+
+class EarlyFusionTransformer(nn.Module):
+    def __init__(self, num_class, dual_head, backbone_3d_kwargs, backbone_2d_kwargs):
+        super(EarlyFusionTransformer, self).__init__()
+        self.dual_head = dual_head
+        self.lidar_backbone = Net3DSeg(num_classes=num_class, dual_head=dual_head, backbone_3d_kwargs=backbone_3d_kwargs)
+        self.image_backbone = image_branch(num_class, dual_head, backbone_2d_kwargs)
+
+    def forward(self, data_dict):
+        preds_image = self.image_backbone(img=data_dict["img"], img_indices=data_dict["img_indices"])
+        # with middle_feat_block_number = 0 the "middle" tap is the early one (early_fusion.py:101-105)
+        preds_lidar = self.lidar_backbone(x=data_dict["lidar"], img_early_feats=preds_image["img_middle_feats"].detach())
+        return fused_outputs(self.dual_head, preds_lidar, preds_image)

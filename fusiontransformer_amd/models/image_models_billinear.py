@@ -1,0 +1,132 @@
+"""Image branch + 2D->3D lift.
+
+Mirror of FusionTransformer/models/image_models_billinear.py:8-155
+(`BilinearModule`, `Net2DBillinear`), same attribute names / state_dict keys.
+
+What changes on MI355X: the reference up-samples each tapped block's 96-channel
+24x24 map to 370x1226 (174 MB fp32 per frame per tap, written in the forward
+and again in the backward) and then picks ~20k pixels out of it.  Here
+Conv1x1 -> ReLU -> BN run on the 24x24 token grid (BN statistics are taken
+before the upsample in the reference too, image_models_billinear.py:20-22), and
+`lift_gather` reads the nearest source cell directly for each point: the
+up-sampled map never exists."""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import functional as spf
+from .transformers import image_2d_distilled_transformer
+
+__all__ = ["BilinearModule", "Net2DBillinear", "pack_img_indices"]
+
+
+def pack_img_indices(img_indices, device):
+    """list[B] of (N_i,2) int64 (row,col) host arrays (data/collate.py:50,73) -> one
+    (sum N,2) int64 device tensor + (sum N,) int32 frame index: ONE H2D per batch
+    instead of the reference's per-frame implicit copies (image_models_billinear.py:118-123).
+    An already packed (idx, frame) pair of device tensors is passed through."""
+    if isinstance(img_indices, tuple) and len(img_indices) == 2 and torch.is_tensor(img_indices[0]):
+        return img_indices
+    arrs = [np.asarray(a.cpu() if torch.is_tensor(a) else a, dtype=np.int64).reshape(-1, 2) for a in img_indices]
+    idx = torch.from_numpy(np.ascontiguousarray(np.concatenate(arrs, 0)))
+    frame = torch.from_numpy(np.concatenate([np.full((a.shape[0],), i, dtype=np.int32) for i, a in enumerate(arrs)]))
+    return idx.to(device, non_blocking=True), frame.to(device, non_blocking=True)
+
+
+class BilinearModule(nn.Module):
+    """Conv1x1 -> ReLU -> BatchNorm2d -> nn.Upsample(size) (nearest, despite the name)."""
+
+    def __init__(self, in_features, out_features, interpolation_output_size):
+        super().__init__()
+        self.stem = nn.Sequential(
+            nn.Conv2d(in_channels=in_features, out_channels=out_features, kernel_size=1),
+            nn.ReLU(True),
+            nn.BatchNorm2d(out_features))
+        self.up = nn.Upsample(interpolation_output_size)   # kept for parity of the module tree; executed by libftx
+        self.size = tuple(interpolation_output_size)
+
+    def forward(self, x):
+        x = self.stem(x)
+        return spf.resample_nearest(x, self.size)
+
+    def forward_tokens(self, tokens, grid_hw):
+        """tokens (B, gh*gw, Cin) -> stem on the token grid -> (B, gh, gw, Cout) channels-last."""
+        B, T, E = tokens.shape
+        conv, bn = self.stem[0], self.stem[2]
+        rows = F.relu(F.linear(tokens.reshape(B * T, E), conv.weight.view(conv.out_channels, E), conv.bias))
+        if bn.training and bn.track_running_stats:
+            bn.num_batches_tracked.add_(1)
+        rows = spf.batch_norm(rows, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps)
+        return rows.view(B, grid_hw[0], grid_hw[1], conv.out_channels)
+
+
+class Net2DBillinear(nn.Module):
+    def __init__(self, num_classes: int, dual_head: bool, backbone_2d_kwargs=dict()):
+        super().__init__()
+        kw = backbone_2d_kwargs
+        self.feat_channels = 96      # channels lifted onto the points
+        self.hidden_channels = 768   # ViT width
+        # the reference hard-codes (370, 1226) (image_models_billinear.py:74,77); other
+        # lift sizes (384x1248, 900x1600) are throughput-only shapes
+        self.lift_size = tuple(kw.get("lift_size", (370, 1226)))
+
+        self.sample_down = BilinearModule(in_features=3, out_features=3, interpolation_output_size=(384, 384))
+
+        if kw.get("middle_feat_block_number", None) is not None:
+            self.middle_feat_block_number = str(kw["middle_feat_block_number"])
+        else:
+            self.middle_feat_block_number = None
+        if kw.get("late_feat_block_number", None) is not None:
+            self.late_feat_block_number = str(kw["late_feat_block_number"])
+        else:
+            self.late_feat_block_number = None
+
+        vit_kwargs = dict(remove_tokens_outputs=True)
+        if kw.get("vit_depth", None) is not None:
+            vit_kwargs["depth"] = int(kw["vit_depth"])
+        if kw.get("skip_unused_blocks", True) and self.late_feat_block_number is not None:
+            taps = [int(self.late_feat_block_number)] + ([int(self.middle_feat_block_number)] if self.middle_feat_block_number else [])
+            vit_kwargs["last_block"] = max(taps)
+        self.backbone = image_2d_distilled_transformer(pretrained=False, **vit_kwargs)
+        if kw.get("IMAGE_PRETRAINED_PATH", "") != "":
+            ckpt = torch.load(kw["IMAGE_PRETRAINED_PATH"], map_location="cpu", weights_only=True)["state_dict"]
+            new_state_dict = OrderedDict((k.replace("backbone.", ""), v) for k, v in ckpt.items() if "backbone" in k)
+            self.backbone.load_state_dict(new_state_dict)
+        self.backbone.set_attention_impl(kw.get("attn_impl", "torch"))
+
+        self.up = nn.ModuleDict()
+        if self.middle_feat_block_number:
+            self.up[self.middle_feat_block_number] = BilinearModule(self.hidden_channels, self.feat_channels, self.lift_size)
+        self.up[self.late_feat_block_number] = BilinearModule(self.hidden_channels, self.feat_channels, self.lift_size)
+
+        self.linear = nn.Linear(self.feat_channels, num_classes)
+        self.dual_head = dual_head
+        if dual_head:
+            self.linear2 = nn.Linear(self.feat_channels, num_classes)
+
+    def get_img_feats(self, img_indices, block_id: str, image_shape: tuple, backbone_output: Dict):
+        """reference image_models_billinear.py:88-126 -> (sum N, 96)."""
+        x = backbone_output[block_id]
+        g = 384 // 16
+        grid = self.up[block_id].forward_tokens(x, (g, g))
+        idx, frame = pack_img_indices(img_indices, x.device)
+        return spf.lift_gather(grid, idx, frame, self.lift_size[0], self.lift_size[1])
+
+    def forward(self, img, img_indices):
+        img_indices = pack_img_indices(img_indices, img.device)
+        x = self.sample_down(img)
+        backbone_output = self.backbone.forward_blocks(x)
+        late_feats = self.get_img_feats(img_indices, self.late_feat_block_number, img.shape, backbone_output)
+        x = self.linear(late_feats)
+        preds = {"img_feats": late_feats, "img_seg_logit": x}
+        if self.dual_head:
+            preds["img_seg_logit2"] = self.linear2(late_feats)
+        if self.middle_feat_block_number:
+            preds["img_middle_feats"] = self.get_img_feats(img_indices, self.middle_feat_block_number, img.shape, backbone_output)
+        return preds

@@ -1,0 +1,51 @@
+"""SegIoU: mirror of FusionTransformer/models/metric.py:26-82, accumulated on the device
+(the reference copies both (sum N, 20) logit tensors to the host every step, metric.py:43-44)."""
+import torch
+
+
+class SegIoU(object):
+    def __init__(self, num_classes, ignore_index=0, name="seg_iou"):
+        self.num_classes = num_classes
+        self.ignore_index = ignore_index
+        self.mat = None
+        self.name = name
+
+    def update_dict(self, preds, labels):
+        if "3d" in self.name:
+            seg_logit = preds["lidar_seg_logit"]
+        if "2d" in self.name:
+            seg_logit = preds["img_seg_logit"]
+        seg_label = labels["seg_label"].detach().long().to(seg_logit.device)
+        pred_label = seg_logit.detach().argmax(1)
+        mask = seg_label != self.ignore_index
+        seg_label = seg_label[mask]
+        pred_label = pred_label[mask]
+        n = self.num_classes
+        with torch.no_grad():
+            if self.mat is None:
+                self.mat = seg_label.new_zeros((n, n))
+            inds = n * seg_label + pred_label
+            self.mat += torch.bincount(inds, minlength=n ** 2).reshape(n, n)
+
+    def reset(self):
+        self.mat = None
+
+    @property
+    def iou(self):
+        h = self.mat.float()
+        return torch.diag(h) / (h.sum(1) + h.sum(0) - torch.diag(h))
+
+    @property
+    def global_avg(self):
+        return self.iou.mean().item()
+
+    @property
+    def avg(self):
+        return self.global_avg
+
+    def __str__(self):
+        return "{iou:.4f}".format(iou=self.iou.mean().item())
+
+    @property
+    def summary_str(self):
+        return str(self)

@@ -1,0 +1,158 @@
+"""DeiT-base-distilled-384 trunk with per-block outputs.
+
+Mirror of FusionTransformer/models/transformers.py:11-45,90-100.  timm is not a
+dependency: the VisionTransformer structure of timm 0.4.9 (PatchEmbed, Block,
+Attention, Mlp; LayerNorm eps 1e-6, exact GELU, qkv_bias=True, distilled) is
+restated here with the same attribute names, so DeiT checkpoints keyed
+`backbone.blocks.0.attn.qkv.weight` etc. load unchanged.
+
+The dense contractions (patch-embed conv, qkv / proj / MLP linears) go through
+torch's hipBLASLt GEMMs; softmax(QK^T/8)V runs in libftx's fused attention
+kernel when `attn_impl == "ftx"`, otherwise as the three explicit ops timm uses."""
+from __future__ import annotations
+
+from functools import partial
+from typing import Dict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+__all__ = ["Image2DTransformer", "image_2d_distilled_transformer"]
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features, drop=0.0):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden_features, in_features)
+        self.drop = nn.Dropout(drop)
+
+    def forward(self, x):
+        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.scale = head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.attn_impl = "torch"
+
+    def forward(self, x):
+        B, N, C = x.shape
+        qkv = self.qkv(x)
+        if self.attn_impl == "ftx":
+            from .. import functional as spf
+            x = spf.attention(qkv.view(B, N, 3, self.num_heads, C // self.num_heads), self.scale)
+        else:
+            qkv = qkv.reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+            q, k, v = qkv[0], qkv[1], qkv[2]
+            attn = (q @ k.transpose(-2, -1)) * self.scale
+            attn = attn.softmax(dim=-1)
+            attn = self.attn_drop(attn)
+            x = (attn @ v).transpose(1, 2).reshape(B, N, C)
+        return self.proj_drop(self.proj(x))
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=True, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias)
+        self.drop_path = nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+    def forward(self, x):
+        x = x + self.drop_path(self.attn(self.norm1(x)))
+        x = x + self.drop_path(self.mlp(self.norm2(x)))
+        return x
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
+        super().__init__()
+        self.img_size = (img_size, img_size)
+        self.patch_size = (patch_size, patch_size)
+        self.num_patches = (img_size // patch_size) ** 2
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.norm = nn.Identity()
+
+    def forward(self, x):
+        return self.norm(self.proj(x).flatten(2).transpose(1, 2))
+
+
+class Image2DTransformer(nn.Module):
+    def __init__(self, remove_tokens_outputs=False, img_size=384, patch_size=16, in_chans=3, embed_dim=768, depth=12, num_heads=12,
+                 mlp_ratio=4.0, qkv_bias=True, distilled=True, last_block=None, **_unused):
+        super().__init__()
+        self.remove_tokens_outputs = remove_tokens_outputs
+        self.num_features = self.embed_dim = embed_dim
+        self.num_tokens = 2 if distilled else 1
+        norm_layer = partial(nn.LayerNorm, eps=1e-6)
+        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.dist_token = nn.Parameter(torch.zeros(1, 1, embed_dim)) if distilled else None
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches + self.num_tokens, embed_dim))
+        self.pos_drop = nn.Dropout(p=0.0)
+        self.blocks = nn.Sequential(*[Block(embed_dim, num_heads, mlp_ratio, qkv_bias, norm_layer) for _ in range(depth)])
+        self.norm = norm_layer(embed_dim)   # kept for checkpoint compatibility; forward_blocks never applies it
+        self.head = nn.Identity()           # reset_classifier(0, '') in image_models_billinear.py:44,57
+        self.head_dist = nn.Identity()
+        # Blocks after `last_block` never influence an output the model returns
+        # (SURVEY Appendix A.12); they are skipped when it is set.
+        self.last_block = last_block
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        nn.init.trunc_normal_(self.cls_token, std=0.02)
+        if self.dist_token is not None:
+            nn.init.trunc_normal_(self.dist_token, std=0.02)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.zeros_(m.bias)
+                nn.init.ones_(m.weight)
+
+    def set_attention_impl(self, impl: str):
+        for blk in self.blocks:
+            blk.attn.attn_impl = impl
+
+    def forward_blocks(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """reference models/transformers.py:16-45: every block's output, cls/dist tokens stripped."""
+        x = self.patch_embed(x)
+        cls_token = self.cls_token.expand(x.shape[0], -1, -1)
+        if self.dist_token is None:
+            x = torch.cat((cls_token, x), dim=1)
+        else:
+            x = torch.cat((cls_token, self.dist_token.expand(x.shape[0], -1, -1), x), dim=1)
+        x = self.pos_drop(x + self.pos_embed)
+        outputs = dict()
+        for i, block in enumerate(self.blocks):
+            if self.last_block is not None and i > self.last_block:
+                break
+            x = block(x)
+            if self.remove_tokens_outputs:
+                outputs[str(i)] = x[:, self.num_tokens:, :]
+            else:
+                outputs[str(i)] = x
+        return outputs
+
+
+def image_2d_distilled_transformer(pretrained=False, **kwargs):
+    """reference models/transformers.py:90-100 (DeiT-base distilled, patch 16, 384x384).
+
+    `pretrained=True` would fetch weights by name; there is no network here, so it is refused."""
+    if pretrained:
+        raise RuntimeError("pretrained DeiT weights cannot be fetched offline; pass IMAGE_PRETRAINED_PATH or use random init")
+    model_kwargs = dict(patch_size=16, embed_dim=768, depth=12, num_heads=12, img_size=384, distilled=True)
+    model_kwargs.update(kwargs)
+    return Image2DTransformer(**model_kwargs)

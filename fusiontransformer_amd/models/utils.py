@@ -1,0 +1,83 @@
+"""initial_voxelize / point_to_voxel / voxel_to_point on the GPU.
+
+Same names, arguments and caching behaviour as the reference's
+FusionTransformer/models/utils.py:15-106; every `spf.*` call there maps to the
+function of the same name in fusiontransformer_amd.functional (libftx)."""
+from __future__ import annotations
+
+import torch
+
+from .. import functional as spf
+from ..sparse import CoordinateManager, PointTensor, SparseTensor
+
+__all__ = ["initial_voxelize", "point_to_voxel", "voxel_to_point"]
+
+
+def initial_voxelize(z: PointTensor, init_res, after_res) -> SparseTensor:
+    """reference models/utils.py:15-35."""
+    if init_res == after_res:
+        new_float_coord = z.C
+    else:
+        new_float_coord = torch.cat([(z.C[:, :3] * init_res) / after_res, z.C[:, -1].view(-1, 1)], 1).contiguous()
+    floored = spf.floor_coords(new_float_coord, 1)           # torch.floor(...).int()
+    pc_hash = spf.sphash(floored)
+    uniq, first, cnt = spf.unique_sorted(pc_hash)            # torch.unique(pc_hash)
+    n_vox = int(cnt.item())
+    sparse_hash = uniq[:n_vox].contiguous()
+    table = spf.HashTable(sparse_hash)
+    idx_query = table.query(pc_hash)                         # spf.sphashquery(pc_hash, sparse_hash)
+    counts = spf.spcount(idx_query, n_vox)
+    # round(mean of identical integer coordinates) == the coordinates of any member
+    inserted_coords = spf.gather_coords(floored, first[:n_vox].contiguous())
+    inserted_feat = spf.spvoxelize(z.F, idx_query, counts)
+
+    new_tensor = SparseTensor(inserted_feat, inserted_coords, 1)
+    new_tensor.cm = CoordinateManager()
+    new_tensor.cm.coords[1] = inserted_coords
+    new_tensor.cm.tables[1] = table                          # keys == sphash(inserted_coords), row order == table rows
+    new_tensor.check()
+    z.additional_features["idx_query"][1] = idx_query
+    z.additional_features["counts"][1] = counts
+    z.C = new_float_coord
+    return new_tensor
+
+
+def point_to_voxel(x: SparseTensor, z: PointTensor) -> SparseTensor:
+    """reference models/utils.py:40-63."""
+    if z.additional_features is None or z.additional_features.get("idx_query") is None \
+            or z.additional_features["idx_query"].get(x.s) is None:
+        pc_hash = spf.sphash(spf.floor_coords(z.C, x.s))
+        idx_query = x.cm.table(x.s).query(pc_hash)           # sphashquery(pc_hash, sphash(x.C))
+        counts = spf.spcount(idx_query, x.C.shape[0])
+        z.additional_features["idx_query"][x.s] = idx_query
+        z.additional_features["counts"][x.s] = counts
+    else:
+        idx_query = z.additional_features["idx_query"][x.s]
+        counts = z.additional_features["counts"][x.s]
+    inserted_feat = spf.spvoxelize(z.F, idx_query, counts)
+    return x.derive(inserted_feat)
+
+
+def voxel_to_point(x: SparseTensor, z: PointTensor, nearest=False) -> PointTensor:
+    """reference models/utils.py:68-106."""
+    if z.idx_query is None or z.weights is None or z.idx_query.get(x.s) is None or z.weights.get(x.s) is None:
+        off = x.cm.offsets(2, x.s, z.F.device)               # KernelRegion(2, x.s, 1)
+        floored = spf.floor_coords(z.C, x.s)
+        # sphash(floored, off) + sphashquery against sphash(x.C), fused; (8, N) -> (N, 8)
+        idx_query = spf.kernel_map_build(floored, off, x.cm.table(x.s)).transpose(0, 1).contiguous()
+        weights = spf.calc_ti_weights(z.C, idx_query, scale=x.s)
+        if nearest:
+            weights[:, 1:] = 0.0
+            idx_query[:, 1:] = -1
+        new_feat = spf.spdevoxelize(x.F, idx_query, weights)
+        new_tensor = PointTensor(new_feat, z.C, idx_query=z.idx_query, weights=z.weights)
+        new_tensor.additional_features = z.additional_features
+        new_tensor.idx_query[x.s] = idx_query
+        new_tensor.weights[x.s] = weights
+        z.idx_query[x.s] = idx_query
+        z.weights[x.s] = weights
+    else:
+        new_feat = spf.spdevoxelize(x.F, z.idx_query.get(x.s), z.weights.get(x.s))
+        new_tensor = PointTensor(new_feat, z.C, idx_query=z.idx_query, weights=z.weights)
+        new_tensor.additional_features = z.additional_features
+    return new_tensor

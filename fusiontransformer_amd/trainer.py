@@ -1,0 +1,67 @@
+"""Train step of the fusion path: the counterpart of SemanticTrainer.train_step
+(FusionTransformer/modules/SemanticTrainer.py:141-209).
+
+Same loss: weighted CE x2 + lambda_xm * KL x2 in the additive form of
+SemanticTrainer.py:158-178, Adam step.  Differences, all behaviour-preserving:
+  * one backward of (loss_2d + loss_3d) instead of two backward calls: the image features enter
+    the LiDAR branch detached (middle_fusion.py:102), so the two loss graphs are disjoint and
+    the summed gradients are identical;
+  * no `.item()` / `.cpu()` host syncs inside the step (the reference has 4+ per step);
+    losses and the IoU confusion matrices stay on the device."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+def fusion_losses(preds, seg_label, class_weights, lambda_xm, dual_head):
+    """(loss_2d, loss_3d) exactly as SemanticTrainer.py:158-178."""
+    seg_label = seg_label.long()
+    loss_3d = F.cross_entropy(preds["lidar_seg_logit"], seg_label, weight=class_weights)
+    loss_2d = F.cross_entropy(preds["img_seg_logit"], seg_label, weight=class_weights)
+    if lambda_xm > 0:
+        seg_logit_2d = preds["img_seg_logit2"] if dual_head else preds["img_seg_logit"]
+        seg_logit_3d = preds["lidar_seg_logit2"] if dual_head else preds["lidar_seg_logit"]
+        xm_loss_2d = F.kl_div(F.log_softmax(seg_logit_2d, dim=1), F.softmax(preds["lidar_seg_logit"].detach(), dim=1),
+                              reduction="none").sum(1).mean()
+        xm_loss_3d = F.kl_div(F.log_softmax(seg_logit_3d, dim=1), F.softmax(preds["img_seg_logit"].detach(), dim=1),
+                              reduction="none").sum(1).mean()
+        loss_2d = loss_2d + lambda_xm * xm_loss_2d
+        loss_3d = loss_3d + lambda_xm * xm_loss_3d
+    return loss_2d, loss_3d
+
+
+def build_optimizer(cfg, model):
+    """common/solver/build.py:7-20: getattr(torch.optim, TYPE)(params, lr, weight_decay)."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    return getattr(torch.optim, cfg.OPTIMIZER.TYPE)(params, lr=cfg.OPTIMIZER.BASE_LR, weight_decay=cfg.OPTIMIZER.WEIGHT_DECAY)
+
+
+class TrainStep:
+    def __init__(self, cfg, model, optimizer=None, metrics=None, grad_reducer=None):
+        self.cfg, self.model = cfg, model
+        self.optimizer = optimizer if optimizer is not None else build_optimizer(cfg, model)
+        dev = next(model.parameters()).device
+        cw = cfg.TRAIN.CLASS_WEIGHTS
+        self.class_weights = torch.tensor(cw, dtype=torch.float32, device=dev) if len(cw) > 0 else None
+        self.lambda_xm = float(cfg.TRAIN.FusionTransformer.lambda_xm)
+        self.dual_head = bool(cfg.MODEL.DUAL_HEAD)
+        self.metrics = metrics or ()
+        self.grad_reducer = grad_reducer
+        self.last = {}
+
+    def __call__(self, data_batch):
+        self.optimizer.zero_grad(set_to_none=False)
+        if self.grad_reducer is not None:
+            self.grad_reducer.begin_step()
+        preds = self.model(data_batch)
+        loss_2d, loss_3d = fusion_losses(preds, data_batch["seg_label"], self.class_weights, self.lambda_xm, self.dual_head)
+        with torch.no_grad():
+            for m in self.metrics:
+                m.update_dict(preds, data_batch)
+        (loss_2d + loss_3d).backward()
+        if self.grad_reducer is not None:
+            self.grad_reducer.finish()
+        self.optimizer.step()
+        self.last = {"loss_2d": loss_2d.detach(), "loss_3d": loss_3d.detach()}
+        return preds

@@ -1,0 +1,155 @@
+/* libftx — C ABI of the MI355X (gfx950) hot path of FusionTransformer.
+ *
+ * The reference (aliabdelkader/FusionTransformer) has no FFI layer of its own:
+ * its native work is reached through torchsparse v1.1.0 (`spf.*`, `spnn.*`),
+ * timm 0.4.9 and torch.  Each entry point below replaces one of those native
+ * ops at the call site cited next to it (paths relative to the reference
+ * root).  The host side (fusiontransformer_amd/) binds these with ctypes; the
+ * binding a reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *     row-major, contiguous; the caller owns every buffer (inputs, outputs and
+ *     workspaces) and the library keeps nothing beyond the call;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it,
+ *     nothing synchronises the host (safe for hipGraph capture) unless stated;
+ *   - return 0 on success, a negative FTX_E* code otherwise; the message is in
+ *     the thread-local ftx_last_error(); nothing throws, nothing aborts;
+ *   - index dtype on the device is int32 (-1 = absent); hashes are int64.
+ */
+#ifndef FTX_H
+#define FTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FTX_OK 0
+#define FTX_EINVAL -1  /* bad argument (null pointer, negative size, unsupported shape) */
+#define FTX_ELAUNCH -2 /* HIP runtime reported an error at launch */
+#define FTX_EWORKSPACE -3 /* workspace too small */
+
+/* library version (major*10000 + minor*100 + patch) and last error text */
+int ftx_version(void);
+const char *ftx_last_error(void);
+
+/* ---- coordinate hashing ------------------------------------------------ */
+
+/* spf.sphash(C): models/utils.py:19,49,79.  coords (n,4) int32 [x,y,z,b] -> out (n) int64. */
+int ftx_hash(const int32_t *coords, int64_t n, int64_t *out, void *stream);
+
+/* spf.sphash(C, off): models/utils.py:74-78.  offsets (k,3) int32 -> out (k,n) int64. */
+int ftx_hash_kernel(const int32_t *coords, int64_t n, const int32_t *offsets, int32_t k, int64_t *out, void *stream);
+
+/* torch.floor(z.C[:, :3] / s).int() * s ++ z.C[:, -1].int(): models/utils.py:44-48,75-78.
+ * pc (n,4) float32 -> out (n,4) int32. */
+int ftx_floor_coords(const float *pc, int64_t n, int32_t stride, int32_t *out, void *stream);
+
+/* ---- hash table (spf.sphashquery): models/utils.py:21,50,80 -------------- */
+
+/* Smallest legal capacity (a power of two >= 2n) for n keys. */
+int64_t ftx_hashtable_capacity(int64_t n);
+/* Build: table_keys (capacity) int64 and table_vals (capacity) int32 are fully
+ * (re)initialised here.  Duplicate keys keep the smallest row index. */
+int ftx_hashtable_build(const int64_t *keys, int64_t n, int64_t *table_keys, int32_t *table_vals, int64_t capacity, void *stream);
+/* Query: out[i] = row of queries[i] in the keys the table was built from, or -1. */
+int ftx_hashtable_query(const int64_t *queries, int64_t nq, const int64_t *table_keys, const int32_t *table_vals, int64_t capacity, int32_t *out, void *stream);
+
+/* spf.spcount(idx, m): models/utils.py:22,51.  counts (m) int32 is zeroed here. */
+int ftx_count(const int32_t *idx, int64_t n, int32_t *counts, int64_t m, void *stream);
+
+/* torch.unique(hash) (sorted): models/utils.py:20 and torchsparse spdownsample.
+ * uniq (n) int64 receives the sorted unique keys, first_index (n) int32 the row of
+ * the first occurrence of each, n_unique (1) int32 (device) their number.
+ * Rows past n_unique are unspecified. */
+size_t ftx_unique_workspace_bytes(int64_t n);
+int ftx_unique_sorted(const int64_t *keys, int64_t n, int64_t *uniq, int32_t *first_index, int32_t *n_unique, void *workspace, size_t workspace_bytes, void *stream);
+
+/* torchsparse spdownsample coordinate rule: floor(c / ratio) * ratio on x,y,z, b kept.
+ * coords (n,4) int32 -> out (n,4) int32.  (inside spnn.Conv3d(stride=2): models/spvcnn.py:105,111,117,123) */
+int ftx_downsample_coords(const int32_t *coords, int64_t n, int32_t ratio, int32_t *out, void *stream);
+
+/* out[i,:] = src[index[i],:] for int32 rows of width 4 (coordinate gather). */
+int ftx_gather_coords(const int32_t *src, const int32_t *index, int64_t n, int32_t *out, void *stream);
+
+/* ---- kernel maps (inside spnn.Conv3d): models/spvcnn.py:26-30,42-46,57-72,99-101 */
+
+/* nbr[k, o] = row in the table's key set of (out_coords[o] + offsets[k]), or -1.
+ * Fuses sphash(out_coords, offsets) + sphashquery.  nbr is (k, n_out) int32. */
+int ftx_kernel_map_build(const int32_t *out_coords, int64_t n_out, const int32_t *offsets, int32_t k, const int64_t *table_keys, const int32_t *table_vals, int64_t capacity, int32_t *nbr, void *stream);
+/* nbr_t[k, i] = o where nbr[k, o] == i, else -1.  nbr_t is (k, n_in) int32, fully written. */
+int ftx_kernel_map_transpose(const int32_t *nbr, int64_t n_out, int64_t n_in, int32_t k, int32_t *nbr_t, void *stream);
+
+/* spf.calc_ti_weights: models/utils.py:81-82.  pc (n,4) float32 (integer-valued or not),
+ * idx (n,8) int32 (point-major, as after the transpose at utils.py:83), weights (n,8) float32. */
+int ftx_trilinear_weights(const float *pc, const int32_t *idx, int64_t n, int32_t scale, float *weights, void *stream);
+
+/* ---- point <-> voxel feature movement ----------------------------------- */
+
+/* spf.spvoxelize fwd: models/utils.py:24-27,58.  out (m,c) is zeroed here;
+ * out[idx[i]] += feats[i] / counts[idx[i]]. */
+int ftx_voxelize_fwd(const float *feats, const int32_t *idx, const int32_t *counts, int64_t n, int32_t c, int64_t m, float *out, void *stream);
+/* bwd: grad_feats[i] = grad_out[idx[i]] / counts[idx[i]] (0 where idx<0). */
+int ftx_voxelize_bwd(const float *grad_out, const int32_t *idx, const int32_t *counts, int64_t n, int32_t c, int64_t m, float *grad_feats, void *stream);
+
+/* spf.spdevoxelize fwd: models/utils.py:87,99.  out[i] = sum_k w[i,k] * feats[idx[i,k]]. */
+int ftx_devoxelize_fwd(const float *feats, const int32_t *idx, const float *weights, int64_t n, int32_t c, int64_t m, float *out, void *stream);
+/* bwd: grad_feats (m,c) zeroed here; grad_feats[idx[i,k]] += w[i,k] * grad_out[i]. */
+int ftx_devoxelize_bwd(const float *grad_out, const int32_t *idx, const float *weights, int64_t n, int32_t c, int64_t m, float *grad_feats, void *stream);
+
+/* ---- 2D -> 3D lift ------------------------------------------------------- */
+
+/* Fused `nn.Upsample((H,W))` (nearest) + per-point gather of
+ * Net2DBillinear.get_img_feats: models/image_models_billinear.py:113,117-124.
+ * grid (b, gh, gw, c) float32 channels-last (= the (B,576,96) token layout);
+ * img_idx (n,2) int64 (row,col) in the (H,W) lift image; point_batch (n) int32;
+ * out (n,c).  The (H,W,c) map is never materialised. */
+int ftx_lift_gather_fwd(const float *grid, const int64_t *img_idx, const int32_t *point_batch, int64_t n, int32_t b, int32_t gh, int32_t gw, int32_t c, int32_t H, int32_t W, float *out, void *stream);
+/* bwd: grad_grid (b,gh,gw,c) zeroed here, scatter-add of grad_out rows. */
+int ftx_lift_gather_bwd(const float *grad_out, const int64_t *img_idx, const int32_t *point_batch, int64_t n, int32_t b, int32_t gh, int32_t gw, int32_t c, int32_t H, int32_t W, float *grad_grid, void *stream);
+
+/* `nn.Upsample((oh,ow))` nearest on NCHW: models/image_models_billinear.py:17,41.
+ * in (b,c,ih,iw) -> out (b,c,oh,ow). bwd zeroes grad_in and scatter-adds. */
+int ftx_resample_nearest_fwd(const float *in, int32_t b, int32_t c, int32_t ih, int32_t iw, int32_t oh, int32_t ow, float *out, void *stream);
+int ftx_resample_nearest_bwd(const float *grad_out, int32_t b, int32_t c, int32_t ih, int32_t iw, int32_t oh, int32_t ow, float *grad_in, void *stream);
+
+/* ---- sparse convolution (spnn.Conv3d fwd/bwd) ---------------------------- */
+
+/* out[r,:] = sum_k A[tbl[k,r],:] @ Wk, rows with tbl<0 contribute nothing.
+ *   A   (rows_a, ca) float32        tbl (kvol, n_out) int32 rows of A
+ *   W   (kvol, ca, co) row-major when w_transposed == 0  (Wk = W[k])
+ *       (kvol, co, ca) row-major when w_transposed == 1  (Wk = W[k]^T)
+ *   out (n_out, co), fully written (no atomics, deterministic).
+ * forward conv: A=in, tbl=nbr, W=kernel; data gradient: A=grad_out, tbl=nbr_t,
+ * w_transposed=1; transposed conv swaps the two tables. */
+int ftx_spconv_gemm(const float *A, int64_t rows_a, const float *W, const int32_t *tbl, int64_t n_out, int32_t ca, int32_t co, int32_t kvol, int32_t w_transposed, float *out, void *stream);
+
+/* dW[k] = sum_r A[tbl[k,r],:]^T @ G[r,:]   -> dW (kvol, ca, cg), fully written.
+ *   A (rows_a, ca), G (n_rows, cg), tbl (kvol, n_rows).
+ * workspace: ftx_spconv_wgrad_workspace_bytes(n_rows, ca, cg, kvol). */
+size_t ftx_spconv_wgrad_workspace_bytes(int64_t n_rows, int32_t ca, int32_t cg, int32_t kvol);
+int ftx_spconv_wgrad(const float *A, int64_t rows_a, const float *G, const int32_t *tbl, int64_t n_rows, int32_t ca, int32_t cg, int32_t kvol, float *dW, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- BatchNorm1d over rows (+residual, +ReLU): spnn.BatchNorm / nn.BatchNorm1d
+ *      models/spvcnn.py:30-31,71-79,100-102,164-180; models/middle_fusion.py:18-22 */
+
+/* Training forward: batch statistics over the n rows (biased var for
+ * normalisation, unbiased for running_var, momentum as torch), then
+ * y = relu?( (x-mean)*invstd*gamma + beta (+ residual) ).
+ * save_mean / save_invstd (c) are outputs for the backward.
+ * running_mean / running_var may be NULL (no update).  residual may be NULL. */
+size_t ftx_bn_workspace_bytes(int64_t n, int32_t c);
+int ftx_bn_train_fwd(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean, float *running_var, float momentum, float eps, int64_t n, int32_t c, int32_t relu, float *y, float *save_mean, float *save_invstd, void *workspace, size_t workspace_bytes, void *stream);
+/* Eval forward with running statistics. */
+int ftx_bn_eval_fwd(const float *x, const float *residual, const float *gamma, const float *beta, const float *running_mean, const float *running_var, float eps, int64_t n, int32_t c, int32_t relu, float *y, void *stream);
+/* Training backward.  y is the forward output (needed for the ReLU mask when relu!=0).
+ * grad_x (n,c), grad_residual (n,c, may be NULL), grad_gamma (c), grad_beta (c). */
+int ftx_bn_train_bwd(const float *grad_y, const float *x, const float *y, const float *gamma, const float *save_mean, const float *save_invstd, int64_t n, int32_t c, int32_t relu, float *grad_x, float *grad_residual, float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FTX_H */

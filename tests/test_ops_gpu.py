@@ -1,0 +1,276 @@
+"""Op-level parity of the libftx kernels against the CPU oracle (bit-exact for integer /
+index work, tight fp32 tolerances for feature movement and sparse conv)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import random_coords
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    from fusiontransformer_amd import functional as spf
+    from oracle import ft_oracle as O
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return spf, O
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_hash_matches_oracle_bit_exact(env):
+    spf, O = env
+    rng = np.random.default_rng(0)
+    c = rng.integers(-5000, 5000, size=(10007, 4)).astype(np.int32)
+    assert np.array_equal(spf.sphash(dev(c)).cpu().numpy(), O.sphash(c))
+    off = O.kernel_offsets(3, 2)
+    assert np.array_equal(spf.sphash(dev(c), dev(off)).cpu().numpy(), O.sphash(c, off))
+    assert np.array_equal(spf.kernel_offsets(3, 2), off) and np.array_equal(spf.kernel_offsets(2, 4), O.kernel_offsets(2, 4))
+
+
+def test_hash_empty_and_single(env):
+    spf, O = env
+    e = torch.zeros((0, 4), dtype=torch.int32, device="cuda")
+    assert spf.sphash(e).shape == (0,)
+    one = np.array([[1, 2, 3, 0]], dtype=np.int32)
+    assert np.array_equal(spf.sphash(dev(one)).cpu().numpy(), O.sphash(one))
+
+
+def test_hashquery_count_unique(env):
+    spf, O = env
+    rng = np.random.default_rng(1)
+    c = random_coords(rng, 5000)
+    h = O.sphash(c)
+    # queries: half present, half absent
+    q = np.concatenate([h[rng.permutation(len(h))[:3000]], O.sphash(c + np.array([1000, 0, 0, 0], dtype=np.int32))[:3000]])
+    got = spf.sphashquery(dev(q), dev(h)).cpu().numpy()
+    assert np.array_equal(got.astype(np.int64), O.sphashquery(q, h))
+    assert (got[3000:] == -1).all()
+    # duplicates in the key list keep the smallest row
+    hd = np.concatenate([h[:100], h[:100]])
+    assert np.array_equal(spf.sphashquery(dev(h[:100]), dev(hd)).cpu().numpy(), np.arange(100))
+    idx = rng.integers(-1, 50, size=4000).astype(np.int32)
+    assert np.array_equal(spf.spcount(dev(idx), 50).cpu().numpy(), O.spcount(idx, 50))
+    # sorted unique with collisions
+    keys = h[rng.integers(0, 700, size=6000)]
+    uniq, first, cnt = spf.unique_sorted(dev(keys))
+    n = int(cnt.item())
+    ref_u, ref_first = np.unique(keys, return_index=True)
+    assert n == len(ref_u)
+    assert np.array_equal(uniq[:n].cpu().numpy(), ref_u)
+    assert np.array_equal(first[:n].cpu().numpy(), ref_first)
+
+
+def test_kernel_maps_bit_exact(env):
+    spf, O = env
+    from fusiontransformer_amd.sparse import CoordinateManager
+    rng = np.random.default_rng(2)
+    c = random_coords(rng, 6000, extent=48, batch=3)
+    # canonical order: ascending hash, as initial_voxelize produces
+    c = c[np.argsort(O.sphash(c))]
+    cm = CoordinateManager()
+    cm.coords[1] = dev(c)
+    for ks, cur, s in [(3, 1, 1), (2, 1, 2), (3, 2, 1), (2, 2, 2), (3, 4, 1)]:
+        km = cm.kernel_map(ks, cur, s)
+        ref_in = cm.coords[cur].cpu().numpy()
+        ref_idx, ref_out = O.build_kernel_map(ref_in, cur, ks, s)
+        assert np.array_equal(km.out_coords.cpu().numpy(), ref_out), (ks, cur, s)
+        assert np.array_equal(km.nbr.cpu().numpy().astype(np.int64), ref_idx), (ks, cur, s)
+        nbr = km.nbr.cpu().numpy()
+        nbr_t = km.nbr_t.cpu().numpy()
+        ref_t = np.full_like(nbr_t, -1)
+        for k in range(nbr.shape[0]):
+            o = np.nonzero(nbr[k] >= 0)[0]
+            ref_t[k, nbr[k, o]] = o
+        assert np.array_equal(nbr_t, ref_t)
+
+
+def test_trilinear_weights_and_floor(env):
+    spf, O = env
+    rng = np.random.default_rng(3)
+    n = 3001
+    pc_int = np.concatenate([rng.integers(0, 300, size=(n, 3)), rng.integers(0, 2, size=(n, 1))], 1).astype(np.float32)
+    pc_frac = pc_int.copy()
+    pc_frac[:, :3] += rng.uniform(0, 0.999, size=(n, 3)).astype(np.float32)
+    for pc in (pc_int, pc_frac):
+        for s in (1, 4, 16):
+            fl = spf.floor_coords(dev(pc), s).cpu().numpy()
+            assert np.array_equal(fl, O._floor_to_stride(pc, s))
+            idx = rng.integers(-1, 100, size=(n, 8)).astype(np.int32)
+            w = spf.calc_ti_weights(dev(pc), dev(idx), s).cpu().numpy()
+            ref = O.calc_ti_weights(pc, idx.T, s).T
+            np.testing.assert_allclose(w, ref, rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("c", [4, 32, 96, 256])
+def test_voxelize_devoxelize_fwd_bwd(env, c):
+    spf, O = env
+    rng = np.random.default_rng(4)
+    n, m = 5000, 700
+    idx = rng.integers(-1, m, size=n).astype(np.int32)
+    counts = O.spcount(idx, m)
+    x = rng.standard_normal((n, c)).astype(np.float32)
+    xo = torch.from_numpy(x).requires_grad_(True)
+    xg = dev(x).requires_grad_(True)
+    yo = O.spvoxelize(xo, idx, counts)
+    yg = spf.spvoxelize(xg, dev(idx), dev(counts))
+    np.testing.assert_allclose(yg.detach().cpu().numpy(), yo.detach().numpy(), rtol=1e-5, atol=1e-5)
+    go = rng.standard_normal(yo.shape).astype(np.float32)
+    yo.backward(torch.from_numpy(go)); yg.backward(dev(go))
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xo.grad.numpy(), rtol=1e-6, atol=1e-6)
+    # devoxelize
+    idx8 = rng.integers(-1, m, size=(n, 8)).astype(np.int32)
+    w8 = rng.uniform(0, 1, size=(n, 8)).astype(np.float32)
+    w8[idx8 < 0] = 0
+    f = rng.standard_normal((m, c)).astype(np.float32)
+    fo = torch.from_numpy(f).requires_grad_(True)
+    fg = dev(f).requires_grad_(True)
+    po = O.spdevoxelize(fo, idx8, w8)
+    pg = spf.spdevoxelize(fg, dev(idx8), dev(w8))
+    np.testing.assert_allclose(pg.detach().cpu().numpy(), po.detach().numpy(), rtol=1e-5, atol=1e-5)
+    g2 = rng.standard_normal(po.shape).astype(np.float32)
+    po.backward(torch.from_numpy(g2)); pg.backward(dev(g2))
+    np.testing.assert_allclose(fg.grad.cpu().numpy(), fo.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("ca,co,ks,cur,s", [(4, 32, 3, 1, 1), (32, 32, 3, 1, 1), (32, 64, 3, 2, 1), (64, 64, 2, 1, 2),
+                                           (128, 96, 3, 1, 1), (192, 128, 3, 2, 1), (384, 256, 3, 4, 1), (256, 256, 2, 2, 2)])
+def test_sparse_conv_fwd_bwd(env, ca, co, ks, cur, s):
+    spf, O = env
+    from fusiontransformer_amd.sparse import CoordinateManager
+    rng = np.random.default_rng(5)
+    c = random_coords(rng, 3000, extent=40, batch=2)
+    c = c[np.argsort(O.sphash(c))]
+    cm = CoordinateManager()
+    cm.coords[1] = dev(c)
+    st = 1
+    while st < cur:  # walk down to the requested level
+        cm.kernel_map(2, st, 2)
+        st *= 2
+    km = cm.kernel_map(ks, cur, s)
+    coords_in = cm.coords[cur].cpu().numpy()
+    idx_query, _ = O.build_kernel_map(coords_in, cur, ks, s)
+    n_in = coords_in.shape[0]
+    x = rng.standard_normal((n_in, ca)).astype(np.float32)
+    w = (rng.standard_normal((ks ** 3, ca, co)) / np.sqrt(ca * ks ** 3)).astype(np.float32)
+    xo, wo = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(w).requires_grad_(True)
+    xg, wg = dev(x).requires_grad_(True), dev(w).requires_grad_(True)
+    yo = O.sparseconv_op(xo, wo, idx_query, km.n_out, False)
+    yg = spf.sparse_conv(xg, wg, km.nbr, km.nbr_t)
+    np.testing.assert_allclose(yg.detach().cpu().numpy(), yo.detach().numpy(), rtol=1e-4, atol=2e-5)
+    go = rng.standard_normal(yo.shape).astype(np.float32)
+    yo.backward(torch.from_numpy(go)); yg.backward(dev(go))
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xo.grad.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(wg.grad.cpu().numpy(), wo.grad.numpy(), rtol=1e-3, atol=2e-4)
+    if s == 2:  # transposed conv on the same map: coarse -> fine
+        xc = rng.standard_normal((km.n_out, co)).astype(np.float32)
+        wt = (rng.standard_normal((ks ** 3, co, ca)) / np.sqrt(co)).astype(np.float32)
+        xco, wto = torch.from_numpy(xc).requires_grad_(True), torch.from_numpy(wt).requires_grad_(True)
+        xcg, wtg = dev(xc).requires_grad_(True), dev(wt).requires_grad_(True)
+        fo = O.sparseconv_op(xco, wto, idx_query, n_in, True)
+        fg = spf.sparse_conv(xcg, wtg, km.nbr_t, km.nbr)
+        np.testing.assert_allclose(fg.detach().cpu().numpy(), fo.detach().numpy(), rtol=1e-4, atol=2e-5)
+        g = rng.standard_normal(fo.shape).astype(np.float32)
+        fo.backward(torch.from_numpy(g)); fg.backward(dev(g))
+        np.testing.assert_allclose(xcg.grad.cpu().numpy(), xco.grad.numpy(), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(wtg.grad.cpu().numpy(), wto.grad.numpy(), rtol=1e-3, atol=2e-4)
+
+
+def test_sparse_conv_is_deterministic(env):
+    spf, O = env
+    from fusiontransformer_amd.sparse import CoordinateManager
+    rng = np.random.default_rng(6)
+    c = random_coords(rng, 4000)
+    c = c[np.argsort(O.sphash(c))]
+    cm = CoordinateManager(); cm.coords[1] = dev(c)
+    km = cm.kernel_map(3, 1, 1)
+    x = dev(rng.standard_normal((4000, 64)).astype(np.float32)).requires_grad_(True)
+    w = dev(rng.standard_normal((27, 64, 64)).astype(np.float32)).requires_grad_(True)
+    outs = []
+    for _ in range(2):
+        x.grad = w.grad = None
+        y = spf.sparse_conv(x, w, km.nbr, km.nbr_t)
+        y.sum().backward()
+        outs.append((y.detach().clone(), x.grad.clone(), w.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n,c,relu,res", [(1000, 32, True, False), (777, 96, True, True), (5000, 256, False, False), (300, 384, True, True), (64, 4, False, False)])
+def test_batch_norm_matches_torch(env, n, c, relu, res):
+    spf, O = env
+    rng = np.random.default_rng(7)
+    x = (rng.standard_normal((n, c)) * 2 + 0.5).astype(np.float32)
+    r = rng.standard_normal((n, c)).astype(np.float32)
+    g, b = rng.uniform(0.5, 1.5, c).astype(np.float32), rng.standard_normal(c).astype(np.float32)
+    bn = torch.nn.BatchNorm1d(c)
+    bn.weight.data, bn.bias.data = torch.from_numpy(g.copy()), torch.from_numpy(b.copy())
+    xo = torch.from_numpy(x).requires_grad_(True)
+    ro = torch.from_numpy(r).requires_grad_(True)
+    yo = bn(xo) + (ro if res else 0)
+    yo = torch.relu(yo) if relu else yo
+    xg, rg = dev(x).requires_grad_(True), dev(r).requires_grad_(True)
+    gg, bg = dev(g).requires_grad_(True), dev(b).requires_grad_(True)
+    rm, rv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    yg = spf.batch_norm(xg, gg, bg, rm, rv, True, 0.1, 1e-5, residual=rg if res else None, relu=relu)
+    np.testing.assert_allclose(yg.detach().cpu().numpy(), yo.detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rm.cpu().numpy(), bn.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rv.cpu().numpy(), bn.running_var.numpy(), rtol=1e-5, atol=1e-6)
+    go = rng.standard_normal((n, c)).astype(np.float32)
+    yo.backward(torch.from_numpy(go)); yg.backward(dev(go))
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xo.grad.numpy(), rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(gg.grad.cpu().numpy(), bn.weight.grad.numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(bg.grad.cpu().numpy(), bn.bias.grad.numpy(), rtol=1e-4, atol=1e-3)
+    if res:
+        np.testing.assert_allclose(rg.grad.cpu().numpy(), ro.grad.numpy(), rtol=1e-6, atol=1e-6)
+    # eval mode uses the running statistics
+    bn.eval()
+    ye = bn(torch.from_numpy(x))
+    yge = spf.batch_norm(dev(x), gg.detach(), bg.detach(), rm, rv, False, 0.1, 1e-5)
+    np.testing.assert_allclose(yge.cpu().numpy(), ye.detach().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_lift_gather_and_resample_match_golden_rule(env):
+    spf, O = env
+    rng = np.random.default_rng(8)
+    B, gh, gw, C, H, W = 2, 24, 24, 96, 370, 1226
+    grid = rng.standard_normal((B, gh, gw, C)).astype(np.float32)
+    idx = [np.stack([rng.integers(0, H, 1500), rng.integers(0, W, 1500)], 1).astype(np.int64) for _ in range(B)]
+    # include the corners
+    idx[0][:4] = [[0, 0], [H - 1, W - 1], [0, W - 1], [H - 1, 0]]
+    from fusiontransformer_amd.models.image_models_billinear import pack_img_indices
+    pi, pb = pack_img_indices(idx, "cuda")
+    gg = dev(grid).requires_grad_(True)
+    out = spf.lift_gather(gg, pi, pb, H, W)
+    # reference: materialise nn.Upsample((H,W)) like image_models_billinear.py:113-124
+    go_t = torch.from_numpy(grid).permute(0, 3, 1, 2).requires_grad_(True)
+    up = torch.nn.Upsample((H, W))(go_t)
+    ref = torch.cat([up.permute(0, 2, 3, 1)[i][torch.from_numpy(idx[i][:, 0]), torch.from_numpy(idx[i][:, 1])] for i in range(B)], 0)
+    assert np.array_equal(out.detach().cpu().numpy(), ref.detach().numpy())
+    g = rng.standard_normal(ref.shape).astype(np.float32)
+    ref.backward(torch.from_numpy(g)); out.backward(dev(g))
+    np.testing.assert_allclose(gg.grad.cpu().numpy(), go_t.grad.permute(0, 2, 3, 1).numpy(), rtol=1e-4, atol=1e-4)
+    # NCHW nearest resample 370x1226 -> 384x384 (sample_down)
+    img = rng.standard_normal((2, 3, 370, 1226)).astype(np.float32)
+    it = torch.from_numpy(img).requires_grad_(True)
+    ref2 = torch.nn.Upsample((384, 384))(it)
+    ig = dev(img).requires_grad_(True)
+    out2 = spf.resample_nearest(ig, (384, 384))
+    assert np.array_equal(out2.detach().cpu().numpy(), ref2.detach().numpy())
+    g2 = rng.standard_normal(ref2.shape).astype(np.float32)
+    ref2.backward(torch.from_numpy(g2)); out2.backward(dev(g2))
+    np.testing.assert_allclose(ig.grad.cpu().numpy(), it.grad.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_bad_arguments_fail_loudly(env):
+    spf, O = env
+    with pytest.raises(ValueError):
+        spf.sphash(torch.zeros((4, 4), dtype=torch.int32))  # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        spf.sphash(torch.zeros((4, 3), dtype=torch.int32, device="cuda"))
+    with pytest.raises(RuntimeError):
+        x = torch.zeros((8, 6), device="cuda")  # channels not a multiple of 4
+        spf._spconv_gemm(x, torch.zeros((27, 6, 8), device="cuda"), torch.zeros((27, 8), dtype=torch.int32, device="cuda"), 8, 8, 0)
