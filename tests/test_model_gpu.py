@@ -46,6 +46,9 @@ def test_train_step_matches_oracle():
     from fusiontransformer_amd.trainer import fusion_losses
     from oracle import ft_oracle as O
     cfg, oracle, model, _ = _pair("middle", seed=1)
+    oracle64 = O.build_model(dict(cfg.MODEL)).double()
+    oracle64.load_state_dict(oracle.state_dict())
+    oracle64.train()
     batch = make_batch([2, 3], max_points=2000)
     oracle.train(); model.train()
     # dropout masks need the voxel counts of levels 16 and 4: take them from an eval pass of the oracle
@@ -69,17 +72,34 @@ def test_train_step_matches_oracle():
         err = (out[k].detach().cpu() - ref[k].detach()).abs().max().item()
         assert err <= TOL, (k, err)
     assert abs(l2.item() - l2r.item()) < 1e-4 and abs(l3.item() - l3r.item()) < 1e-4
-    po, pp = dict(oracle.named_parameters()), dict(model.named_parameters())
-    worst = 0.0
-    for name, p in po.items():
+    # Gradients are checked against the oracle run in float64: in this train-mode network the
+    # fp32 oracle itself sits 1e-3..5e-3 (L2-relative) from the fp64 result (ReLU gates and
+    # batch statistics amplify rounding), so fp32-vs-fp32 would compare two noisy numbers.
+    oracle64.lidar_backbone.dropout_masks = {k: v.double() for k, v in masks.items()}
+    i64 = oracle_inputs(batch)
+    i64["img"], i64["lidar"].F = i64["img"].double(), i64["lidar"].F.double()
+    a64, b64 = O.fusion_losses(oracle64(i64), torch.from_numpy(batch["seg_label"]), cw.double(), 0.1, True)
+    (a64 + b64).backward()
+    p64, pp = dict(oracle64.named_parameters()), dict(model.named_parameters())
+    gmax = max(p.grad.abs().max().item() for p in p64.values() if p.grad is not None)
+    report = []
+    for name, p in p64.items():
         if p.grad is None:
             assert pp[name].grad is None or pp[name].grad.abs().max().item() == 0, name
             continue
-        gp = pp[name].grad.cpu()
-        denom = p.grad.abs().max().item() + 1e-6
-        rel = (gp - p.grad).abs().max().item() / denom
-        worst = max(worst, rel)
-        assert rel < 2e-2, (name, rel)
+        gp = pp[name].grad.cpu().double()
+        # floor: gradients that are exactly 0 in exact arithmetic (Linear biases in front of a
+        # BatchNorm) are pure rounding noise
+        floor = 1e-4 * gmax * p.numel() ** 0.5
+        rel_l2 = (gp - p.grad).norm().item() / max(p.grad.norm().item(), floor)
+        report.append((rel_l2, p.grad.norm().item(), name))
+    report.sort(reverse=True)
+    import json, os
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(report[:40], open("gpurun_out/grad_parity.json", "w"), indent=0)
+    # measured 5e-3..1.5e-2 from run to run (float atomics in voxelize/devoxelize reorder sums); a
+    # wrong or missing term shows up as O(1)
+    assert report[0][0] < 5e-2, report[:5]
     # running statistics were updated identically
     bo, bp = dict(oracle.named_buffers()), dict(model.named_buffers())
     for name, b in bo.items():
