@@ -1,0 +1,230 @@
+#!/usr/bin/env python
+"""Throughput bench of the fusion forward+backward(+Adam) step on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver
+launches it under torch.distributed.run, one rank per GPU (RCCL).  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1], per-GPU batch of configs[3]): synthetic
+SemanticKITTI-shaped frames (370x1226 image, ~20k front-camera points each),
+MiddleFusionTransformer with the full DeiT-base-distilled-384 trunk and SPVCNN, fp32,
+forward + loss (CE x2 + 0.1*KL x2) + backward + Adam, inputs resident in HBM.  `--batch`
+frames per GPU per step (default 4 = configs[3]'s 32 global / 8 GPUs), weak scaling.
+
+A "step" is one pass of the hot path over one batch.  `value` = frames of all ranks per
+second, timed over exactly K steps between barrier + synchronize pairs, max over ranks."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+MFMA_F32_PEAK_TFLOPS = 157.3  # exact-fp32 MFMA peak (same guide)
+
+
+def build_inputs(cfg, batch, shape, rank, device):
+    from fusiontransformer_amd.data.synth import make_batch
+    from fusiontransformer_amd.models.image_models_billinear import pack_img_indices
+    from fusiontransformer_amd.sparse import SparseTensor
+    b = make_batch([rank * batch + i for i in range(batch)], shape=shape)
+    data = {
+        "img": torch.from_numpy(b["img"]).to(device),
+        "img_indices": pack_img_indices(b["img_indices"], device),
+        "lidar": SparseTensor(torch.from_numpy(b["feats"]).to(device), torch.from_numpy(b["coords"]).int().to(device)),
+        "seg_label": torch.from_numpy(b["seg_label"]).to(device),
+    }
+    return b, data
+
+
+def spconv_roofline(log):
+    """Algorithmic bytes / HIP-event time over the sparse-conv launches of one timed step.
+
+    Per (in,out) pair the unit is 4*(ca+co) bytes (gather ca floats + scatter/write
+    co floats), plus the kernel weights 4*kvol*ca*co read once per launch."""
+    pair_cache = {}
+    tot_bytes = tot_ms = tot_flops = 0.0
+    per_kind = {}
+    for kind, e0, e1, tbl, m in log:
+        key = tbl.data_ptr()
+        if key not in pair_cache:
+            pair_cache[key] = int((tbl >= 0).sum().item())
+        pairs = pair_cache[key]
+        nbytes = 4.0 * pairs * (m["ca"] + m["co"]) + 4.0 * m["kvol"] * m["ca"] * m["co"]
+        flops = 2.0 * pairs * m["ca"] * m["co"]
+        ms = e0.elapsed_time(e1)
+        tot_bytes += nbytes
+        tot_ms += ms
+        tot_flops += flops
+        k = per_kind.setdefault(kind, [0, 0.0, 0.0, 0.0])
+        k[0] += 1
+        k[1] += ms
+        k[2] += nbytes
+        k[3] += flops
+    if tot_ms <= 0:
+        return None
+    achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
+    return {
+        "bound": "hbm", "kernel": "spconv_gemm_kernel+spconv_wgrad_kernel (sparse conv fwd / dgrad / wgrad)",
+        "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+        "traffic": None,
+        "launches": len(log), "avg_launch_us": round(1e3 * tot_ms / len(log), 2),
+        "algorithmic_bytes_per_step": int(tot_bytes), "useful_tflops": round(tot_flops / (tot_ms * 1e-3) / 1e12, 3),
+        "mfma_f32_peak_tflops": MFMA_F32_PEAK_TFLOPS,
+        "per_kernel": {k: {"launches": v[0], "ms": round(v[1], 3), "GB/s": round(v[2] / (v[1] * 1e-3) / 1e9, 1),
+                           "useful_TFLOP/s": round(v[3] / (v[1] * 1e-3) / 1e12, 2)} for k, v in per_kind.items()},
+    }
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity mask and cgroup quota, not the host's core count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 32))
+
+
+def log(msg):
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(cfg, np_batch):
+    """The CPU restatement of the reference (oracle/), forward+backward on ONE frame of the same
+    synthetic workload: 1 untimed warm-up + 2 timed passes (~25 s of CPU work)."""
+    from oracle import ft_oracle as O
+    from fusiontransformer_amd.data.synth import make_batch
+    nthreads = host_cores()
+    torch.set_num_threads(nthreads)
+    torch.manual_seed(0)
+    model = O.build_model(dict(cfg.MODEL))
+    model.train()
+    b = make_batch([0])
+    cw = torch.tensor(cfg.TRAIN.CLASS_WEIGHTS)
+    lab = torch.from_numpy(b["seg_label"])
+
+    def one():
+        model.zero_grad()
+        inp = {"img": torch.from_numpy(b["img"]), "img_indices": b["img_indices"], "lidar": O.SparseTensor(torch.from_numpy(b["feats"]), b["coords"])}
+        out = model(inp)
+        l2, l3 = O.fusion_losses(out, lab, cw, float(cfg.TRAIN.FusionTransformer.lambda_xm), True)
+        (l2 + l3).backward()
+
+    log("cpu_baseline: oracle warm-up pass on %d threads" % nthreads)
+    one()
+    times = []
+    for _ in range(2):
+        t = time.perf_counter()
+        one()
+        times.append(time.perf_counter() - t)
+        log("cpu_baseline: pass %.1f s" % times[-1])
+    return {"value": round(1.0 / float(np.median(times)), 4), "unit": "frames/s", "cores": nthreads, "kind": "port",
+            "sample": "1 synthetic SemanticKITTI frame (%d points), fwd+bwd, batch 1, 1 warm-up + 2 timed passes, torch CPU fp32 (CPU restatement of the reference, oracle/ft_oracle.py)" % b["coords"].shape[0]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4, help="frames per GPU per step")
+    ap.add_argument("--shape", default="kitti", choices=["kitti", "nuscenes"])
+    ap.add_argument("--kind", default="middle", choices=["middle", "early", "late"])
+    ap.add_argument("--attn", default=os.environ.get("FTX_ATTN", "torch"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from fusiontransformer_amd import functional as spf
+    from fusiontransformer_amd.config import fusion_cfg
+    from fusiontransformer_amd.data.synth import SHAPES
+    from fusiontransformer_amd.dist import GradReducer, init_process_group
+    from fusiontransformer_amd.models.build import build_model
+    from fusiontransformer_amd.trainer import TrainStep
+
+    rank, world, local_rank = init_process_group()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    cfg = fusion_cfg(args.kind)
+    cfg.MODEL.attn_impl = args.attn
+    cfg.MODEL.lift_size = (SHAPES[args.shape]["H"], SHAPES[args.shape]["W"])
+    torch.manual_seed(0)
+    model, m2d, m3d = build_model(cfg)
+    model = model.to(device).train()
+    reducer = GradReducer(model) if world > 1 else None
+    step = TrainStep(cfg, model, metrics=(m2d, m3d), grad_reducer=reducer)
+    np_batch, data = build_inputs(cfg, args.batch, args.shape, rank, device)
+    n_points = int(np_batch["coords"].shape[0])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if rank == 0:
+        log("model and %d-point batch resident; warm-up" % n_points)
+    for _ in range(args.warmup):
+        step(data)
+    barrier()
+    if rank == 0:
+        log("timing %d steps" % args.steps)
+    t0 = time.perf_counter()
+    launch_log = None
+    for i in range(args.steps):
+        if rank == 0 and i == args.steps - 1:
+            launch_log = spf.LAUNCH_LOG = []   # HIP events around every sparse-conv launch of the last timed step
+        step(data)
+    spf.LAUNCH_LOG = None
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        log("%.1f ms/step" % (1e3 * elapsed / args.steps))
+        frames = args.batch * world * args.steps
+        roof = spconv_roofline(launch_log) if launch_log else None
+        out = {
+            "metric": "frames/sec fwd+bwd (SemanticKITTI synth), whole job",
+            "value": round(frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1] frame shape at configs[3] per-GPU batch: %s-shaped synthetic frames, %dx%d image, "
+                                   "%d points/batch, %sFusionTransformer (DeiT-B/16-384 distilled + SPVCNN), fwd+loss+bwd+Adam, fp32, random-init weights"
+                                   % (args.shape, SHAPES[args.shape]["H"], SHAPES[args.shape]["W"], n_points, args.kind.capitalize()),
+                       "frames_per_gpu": args.batch, "global_batch": args.batch * world, "points_per_gpu_batch": n_points,
+                       "attention": args.attn, "parallelism": "dp%d" % world},
+            "frames_per_sec_per_gpu": round(frames / elapsed / world, 3),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, np_batch)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -232,13 +232,33 @@ def spdevoxelize(feats, idx, weights):
 
 
 # ---------------------------------------------------------------- sparse convolution
+# When set to a list, every sparse-conv launch appends (kind, start_event, end_event, table,
+# shape dict): HIP events recorded on the launch stream, read back by bench.py after the step.
+LAUNCH_LOG = None
+
+
+def _log_launch(kind, tbl, meta, launch):
+    if LAUNCH_LOG is None:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = launch()
+    e1.record()
+    LAUNCH_LOG.append((kind, e0, e1, tbl, meta))
+    return out
+
+
 def _spconv_gemm(A, W, tbl, n_out, co, w_transposed):
     L = _lib.load()
     rows_a, ca = A.shape
     kvol = tbl.shape[0]
     out = _empty((n_out, co), F32, A)
-    check(L.ftx_spconv_gemm(ptr(A), rows_a, ptr(W), ptr(tbl), n_out, ca, co, kvol, int(w_transposed), ptr(out), stream()), "ftx_spconv_gemm")
-    return out
+
+    def launch():
+        check(L.ftx_spconv_gemm(ptr(A), rows_a, ptr(W), ptr(tbl), n_out, ca, co, kvol, int(w_transposed), ptr(out), stream()), "ftx_spconv_gemm")
+        return out
+
+    return _log_launch("spconv_gemm", tbl, dict(n_out=n_out, ca=ca, co=co, kvol=kvol), launch)
 
 
 def _spconv_wgrad(A, G, tbl, kvol):
@@ -248,8 +268,12 @@ def _spconv_wgrad(A, G, tbl, kvol):
     dW = _empty((kvol, ca, cg), F32, A)
     ws_bytes = int(L.ftx_spconv_wgrad_workspace_bytes(n_rows, ca, cg, kvol))
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=A.device)
-    check(L.ftx_spconv_wgrad(ptr(A), rows_a, ptr(G), ptr(tbl), n_rows, ca, cg, kvol, ptr(dW), ptr(ws), ws_bytes, stream()), "ftx_spconv_wgrad")
-    return dW
+
+    def launch():
+        check(L.ftx_spconv_wgrad(ptr(A), rows_a, ptr(G), ptr(tbl), n_rows, ca, cg, kvol, ptr(dW), ptr(ws), ws_bytes, stream()), "ftx_spconv_wgrad")
+        return dW
+
+    return _log_launch("spconv_wgrad", tbl, dict(n_out=n_rows, ca=ca, co=cg, kvol=kvol), launch)
 
 
 class _SparseConv(torch.autograd.Function):

@@ -99,6 +99,17 @@ class Net2DBillinear(nn.Module):
             new_state_dict = OrderedDict((k.replace("backbone.", ""), v) for k, v in ckpt.items() if "backbone" in k)
             self.backbone.load_state_dict(new_state_dict)
         self.backbone.set_attention_impl(kw.get("attn_impl", "torch"))
+        # Parameters that can never receive a gradient (the reference needs
+        # find_unused_parameters=True for them, TorchpackInterface.py:81): the final `norm`
+        # (forward_blocks never applies it) and blocks past the last tap.  Their .grad stays None
+        # in the reference, so its optimizer never touches them; freezing them is the same thing.
+        for p in self.backbone.norm.parameters():
+            p.requires_grad_(False)
+        if self.backbone.last_block is not None:
+            for i, blk in enumerate(self.backbone.blocks):
+                if i > self.backbone.last_block:
+                    for p in blk.parameters():
+                        p.requires_grad_(False)
 
         self.up = nn.ModuleDict()
         if self.middle_feat_block_number:

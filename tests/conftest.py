@@ -16,3 +16,17 @@ def pytest_configure(config):
 def ftx_lib():
     from fusiontransformer_amd import _lib
     return _lib.load()
+
+
+def pytest_sessionstart(session):
+    # the oracle runs on the CPU: use the cores this process really has (cgroup quota), not the host's
+    import torch
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (AttributeError, OSError, ValueError):
+        pass
+    torch.set_num_threads(max(1, min(n, 16)))
