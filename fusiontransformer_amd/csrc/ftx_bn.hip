@@ -85,15 +85,28 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict
   }
 }
 
-__global__ void bn_finalize_fwd_kernel(const double *__restrict__ part, int nb, int64_t n, int c, float eps, float momentum,
-                                       float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ save_mean,
-                                       float *__restrict__ save_invstd) {
-  for (int col = blockIdx.x * blockDim.x + threadIdx.x; col < c; col += gridDim.x * blockDim.x) {
-    double s = 0, ss = 0;
-    for (int b = 0; b < nb; ++b) {
-      s += part[((int64_t)b * 2 + 0) * c + col];
-      ss += part[((int64_t)b * 2 + 1) * c + col];
-    }
+// One wave per channel: lanes stride over the per-block partials, then a shuffle tree.
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const double *__restrict__ part, int nb, int64_t n, int c, float eps,
+                                                              float momentum, float *__restrict__ running_mean,
+                                                              float *__restrict__ running_var, float *__restrict__ save_mean,
+                                                              float *__restrict__ save_invstd) {
+  const int lane = threadIdx.x & 63;
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (col >= c) return;
+  double s = 0, ss = 0;
+  for (int b = lane; b < nb; b += 64) {
+    s += part[((int64_t)b * 2 + 0) * c + col];
+    ss += part[((int64_t)b * 2 + 1) * c + col];
+  }
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  if (lane == 0) {
     double mean = s / (double)n;
     double var = ss / (double)n - mean * mean;
     if (var < 0) var = 0;
@@ -162,7 +175,7 @@ extern "C" int ftx_bn_train_fwd(const float *x, const float *residual, const flo
   const int nb = bn_blocks(n);
   double *part = (double *)workspace;
   bn_partial_kernel<FwdOp><<<nb, 256, bn_partial_lds(c), st>>>(x, nullptr, nullptr, nullptr, nullptr, 0, n, c, part);
-  bn_finalize_fwd_kernel<<<ceil_div(c, 256), 256, 0, st>>>(part, nb, n, c, eps, momentum, running_mean, running_var, save_mean, save_invstd);
+  bn_finalize_fwd_kernel<<<ceil_div(c, 4), 256, 0, st>>>(part, nb, n, c, eps, momentum, running_mean, running_var, save_mean, save_invstd);
   bn_apply_fwd_kernel<<<grid_for(n * (c / 4), 256), 256, 0, st>>>(x, residual, gamma, beta, save_mean, save_invstd, n, c, relu, y);
   return check_launch("ftx_bn_train_fwd");
 }
@@ -202,14 +215,19 @@ extern "C" int ftx_bn_eval_fwd(const float *x, const float *residual, const floa
   return check_launch("ftx_bn_eval_fwd");
 }
 
-__global__ void bn_finalize_bwd_kernel(const double *__restrict__ part, int nb, int c, double *__restrict__ sums,
-                                       float *__restrict__ grad_gamma, float *__restrict__ grad_beta) {
-  for (int col = blockIdx.x * blockDim.x + threadIdx.x; col < c; col += gridDim.x * blockDim.x) {
-    double s = 0, ss = 0;
-    for (int b = 0; b < nb; ++b) {
-      s += part[((int64_t)b * 2 + 0) * c + col];
-      ss += part[((int64_t)b * 2 + 1) * c + col];
-    }
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const double *__restrict__ part, int nb, int c, double *__restrict__ sums,
+                                                              float *__restrict__ grad_gamma, float *__restrict__ grad_beta) {
+  const int lane = threadIdx.x & 63;
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (col >= c) return;
+  double s = 0, ss = 0;
+  for (int b = lane; b < nb; b += 64) {
+    s += part[((int64_t)b * 2 + 0) * c + col];
+    ss += part[((int64_t)b * 2 + 1) * c + col];
+  }
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  if (lane == 0) {
     sums[col] = s;
     sums[c + col] = ss;
     if (grad_beta) grad_beta[col] = (float)s;
@@ -269,7 +287,7 @@ extern "C" int ftx_bn_train_bwd(const float *grad_y, const float *x, const float
   double *part = (double *)workspace;
   double *sums = part + (size_t)nb * 2 * c;
   bn_partial_kernel<BwdOp><<<nb, 256, bn_partial_lds(c), st>>>(x, grad_y, relu ? y : nullptr, save_mean, save_invstd, relu, n, c, part);
-  bn_finalize_bwd_kernel<<<ceil_div(c, 256), 256, 0, st>>>(part, nb, c, sums, grad_gamma, grad_beta);
+  bn_finalize_bwd_kernel<<<ceil_div(c, 4), 256, 0, st>>>(part, nb, c, sums, grad_gamma, grad_beta);
   bn_apply_bwd_kernel<<<grid_for(n * (c / 4), 256), 256, 0, st>>>(grad_y, x, y, gamma, save_mean, save_invstd, sums, n, c, relu, grad_x,
                                                                    grad_residual);
   return check_launch("ftx_bn_train_bwd");

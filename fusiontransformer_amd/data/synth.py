@@ -52,7 +52,9 @@ IMAGENET_STD = np.array([0.229, 0.224, 0.225], dtype=np.float32)
 SHAPES = {
     # name: (H, W, beams, elev_lo, elev_hi, az_half_deg, az_step_deg, fx, cx, cy)
     "kitti": dict(H=370, W=1226, beams=64, elev=(-24.8, 2.0), az_half=45.0, az_step=0.09, f=718.856, cx=607.1928, cy=185.2157),
-    "nuscenes": dict(H=900, W=1600, beams=32, elev=(-30.0, 10.0), az_half=35.0, az_step=0.08, f=1266.4, cx=816.27, cy=491.5),
+    # throughput-only shape (BASELINE configs[2]: 900x1600 image, ~30k points): the beam fan is the part of the
+    # sensor that falls inside the camera frustum, sampled so that ~30k voxels survive the 5 cm dedupe
+    "nuscenes": dict(H=900, W=1600, beams=64, elev=(-19.0, 12.0), az_half=35.0, az_step=0.05, f=1266.4, cx=816.27, cy=491.5),
 }
 
 
@@ -97,6 +99,29 @@ def _raycast_scene(rng, shape):
     return pts.astype(np.float32)
 
 
+def project_points(points, proj_matrix, width, height):
+    """LiDAR -> image projection, statement for statement preprocess.py:108-116.
+
+    Returns (keep mask over `points`, points_img (row, col) float for the kept points)."""
+    keep = points[:, 0] > 0
+    hc = np.concatenate([points[keep], np.ones([int(keep.sum()), 1], dtype=np.float32)], axis=1)
+    img_points = (proj_matrix @ hc.T).T
+    img_points = img_points[:, :2] / np.expand_dims(img_points[:, 2], axis=1)
+    in_img = (img_points[:, 0] > 0) * (img_points[:, 1] > 0) * (img_points[:, 0] < width) * (img_points[:, 1] < height)
+    keep[keep] = in_img
+    return keep, np.fliplr(img_points)[in_img]
+
+
+def scale_points_to_voxels(points, scale, full_scale):
+    """augment_and_scale_3d without augmentation (augmentation_3d.py:41-44) + int cast and
+    in-range mask (semantic_kitti_dataloader.py:216-225).  Returns (coords int64, valid mask)."""
+    coords = points * scale
+    coords -= coords.min(0)
+    coords = coords.astype(np.int64)
+    valid = (coords.min(1) >= 0) * (coords.max(1) < full_scale)
+    return coords, valid
+
+
 def make_frame(seed: int, shape: str = "kitti", scale: int = 20, full_scale: int = 4096, max_points=None):
     """One synthetic frame as the dict SemanticKITTISCN.__getitem__ would return.
 
@@ -106,23 +131,12 @@ def make_frame(seed: int, shape: str = "kitti", scale: int = 20, full_scale: int
     rng = np.random.default_rng(seed)
     points = _raycast_scene(rng, shape)
     intensity = rng.uniform(0.0, 1.0, size=(points.shape[0], 1)).astype(np.float32)
-    # projection (preprocess.py:108-116)
-    keep = points[:, 0] > 0
-    hc = np.concatenate([points[keep], np.ones([int(keep.sum()), 1], dtype=np.float32)], axis=1)
-    img_points = (_proj_matrix(shape) @ hc.T).T
-    img_points = img_points[:, :2] / np.expand_dims(img_points[:, 2], axis=1)
-    in_img = (img_points[:, 0] > 0) * (img_points[:, 1] > 0) * (img_points[:, 0] < s["W"]) * (img_points[:, 1] < s["H"])
-    keep[keep] = in_img
-    img_points = np.fliplr(img_points)[in_img]
+    keep, img_points = project_points(points, _proj_matrix(shape), s["W"], s["H"])
     points = points[keep]
     feats = np.concatenate([points, intensity[keep]], 1).astype(np.float32)
     seg_label = rng.choice(20, size=points.shape[0], p=_CLASS_FREQ).astype(np.int64)
     img_indices = img_points.astype(np.int64)
-    # augment_and_scale_3d without augmentation (augmentation_3d.py:41-44)
-    coords = points * scale
-    coords -= coords.min(0)
-    coords = coords.astype(np.int64)
-    valid = (coords.min(1) >= 0) * (coords.max(1) < full_scale)
+    coords, valid = scale_points_to_voxels(points, scale, full_scale)
     coords, feats, seg_label, img_indices = coords[valid], feats[valid], seg_label[valid], img_indices[valid]
     # dedupe: first point per voxel in sorted-key order
     key = (coords[:, 0] * full_scale + coords[:, 1]) * full_scale + coords[:, 2]

@@ -52,7 +52,15 @@ class BilinearModule(nn.Module):
         self.size = tuple(interpolation_output_size)
 
     def forward(self, x):
-        x = self.stem(x)
+        # stem = Conv1x1 -> ReLU -> BN2d on the full-resolution map (the batch statistics need
+        # every pixel); the 1x1 conv is a channel contraction
+        conv, bn = self.stem[0], self.stem[2]
+        w = conv.weight.view(conv.out_channels, conv.in_channels)
+        x = torch.einsum("oc,bchw->bohw", w, x) + conv.bias.view(1, -1, 1, 1)
+        x = F.relu(x)
+        x = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
+        if bn.training and bn.track_running_stats:
+            bn.num_batches_tracked.add_(1)
         return spf.resample_nearest(x, self.size)
 
     def forward_tokens(self, tokens, grid_hw):

@@ -86,7 +86,13 @@ class PatchEmbed(nn.Module):
         self.norm = nn.Identity()
 
     def forward(self, x):
-        return self.norm(self.proj(x).flatten(2).transpose(1, 2))
+        # Conv2d(k=16, s=16) == non-overlapping unfold + one GEMM (hipBLASLt); same arithmetic as
+        # timm's self.proj(x).flatten(2).transpose(1, 2) without a convolution-library search
+        B, C, H, W = x.shape
+        ph, pw = self.patch_size
+        gh, gw = H // ph, W // pw
+        patches = x.reshape(B, C, gh, ph, gw, pw).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * ph * pw)
+        return self.norm(F.linear(patches, self.proj.weight.view(self.proj.out_channels, -1), self.proj.bias))
 
 
 class Image2DTransformer(nn.Module):

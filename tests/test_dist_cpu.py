@@ -1,0 +1,75 @@
+"""world_size-2 gloo test of the gradient reducer (the N>1 path of bench.py) on the CPU."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from fusiontransformer_amd.dist import GradReducer, init_process_group
+    r, w, _ = init_process_group("gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)   # different initial weights per rank: the reducer must broadcast rank 0's
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+    for p in model[4].parameters():
+        pass
+    frozen = torch.nn.Linear(4, 4)           # never used: must not break the exchange
+    for p in frozen.parameters():
+        p.requires_grad_(False)
+    model.add_module("frozen", frozen)
+    red = GradReducer(model, bucket_mb=0.0005)   # tiny buckets -> several all-reduces, order matters
+    w0 = [p.detach().clone() for p in model.parameters()]
+    gathered = [torch.zeros_like(w0[0]) for _ in range(world)]
+    dist.all_gather(gathered, w0[0])
+    assert all(torch.equal(g, gathered[0]) for g in gathered), "parameters not broadcast"
+    # a twin without the reducer yields this rank's purely local gradients (once buckets overlap
+    # with the backward, p.grad of the reduced model is already averaged when backward returns)
+    twin = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+    twin.load_state_dict({k: v for k, v in model.state_dict().items() if not k.startswith("frozen")})
+    ok = True
+    for step in range(4):
+        torch.manual_seed(1000 + 10 * step + rank)
+        x = torch.randn(5, 8)
+        for p in model.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+        twin.zero_grad()
+        twin(x).pow(2).sum().backward()
+        local = [p.grad.detach().clone() for p in twin.parameters()]
+        red.begin_step()
+        loss = model[:5](x).pow(2).sum()
+        loss.backward()
+        red.finish()
+        # reference: average of the per-rank local gradients
+        for p, g_local in zip([p for p in model.parameters() if p.requires_grad], local):
+            parts = [torch.zeros_like(g_local) for _ in range(world)]
+            dist.all_gather(parts, g_local)
+            ref = sum(parts) / world
+            ok = ok and torch.allclose(p.grad, ref, atol=1e-6)
+    q.put((rank, ok, red._rebuilt, len(red.buckets)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, rebuilt, nb in res:
+        assert ok, f"rank {rank}: reduced gradients differ from the average of the local ones"
+        assert rebuilt and nb > 1

@@ -1,0 +1,107 @@
+"""The oracle (and the host-side pieces that run on the CPU) against the golden vectors that
+tests/golden/make_golden.py produced by running the reference's own importable code."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ft_oracle as O
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def test_nearest_index_rule_matches_nn_upsample():
+    for key, ref in load("upsample_index.npz").items():
+        n_in, n_out = map(int, key.split("_"))
+        assert np.array_equal(O.nearest_src_index(n_out, n_in), ref), key
+
+
+def _load_bilinear(prefix, g, inc, outc, size):
+    m = O.BilinearModule(inc, outc, size)
+    sd = {k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)}
+    m.load_state_dict(sd)
+    return m.train()
+
+
+def test_bilinear_module_down_matches_reference():
+    g = load("bilinear_lift.npz")
+    down = _load_bilinear("down.", g, 3, 3, (384, 384))
+    img = torch.from_numpy(g["img_q"].astype(np.float32) / 256.0)
+    out = down(img).detach().numpy()
+    np.testing.assert_allclose(out, g["down_out"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(down.stem[2].running_mean.numpy(), g["down_running_mean_after"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(down.stem[2].running_var.numpy(), g["down_running_var_after"], rtol=1e-6, atol=1e-7)
+
+
+def test_lift_gather_matches_reference_get_img_feats():
+    g = load("bilinear_lift.npz")
+    net = O.Net2DBillinear.__new__(O.Net2DBillinear)
+    torch.nn.Module.__init__(net)
+    net.up = torch.nn.ModuleDict({"5": _load_bilinear("up.", g, 768, 96, (370, 1226))})
+    tokens = torch.from_numpy(g["tok_q"].astype(np.float32) / 32.0)
+    feats = net.get_img_feats([g["idx0"], g["idx1"]], "5", {"5": tokens}).detach().numpy()
+    np.testing.assert_allclose(feats, g["feats"], rtol=1e-5, atol=1e-6)
+
+
+def test_losses_and_seg_iou_match_reference():
+    g = load("losses_metric.npz")
+    preds = {k: torch.from_numpy(g[k]) for k in ("lidar_seg_logit", "img_seg_logit", "lidar_seg_logit2", "img_seg_logit2")}
+    label = torch.from_numpy(g["label"])
+    cw = torch.from_numpy(g["class_weights"])
+    l2, l3 = O.fusion_losses(preds, label, cw, float(g["lambda_xm"]), True)
+    assert abs(l2.item() - float(g["loss_2d"])) < 1e-6 and abs(l3.item() - float(g["loss_3d"])) < 1e-6
+    assert np.array_equal(O.confusion_matrix(preds["lidar_seg_logit"], label, 20).numpy(), g["mat3d"])
+    assert np.array_equal(O.confusion_matrix(preds["img_seg_logit"], label, 20).numpy(), g["mat2d"])
+    np.testing.assert_allclose(O.iou_from_matrix(torch.from_numpy(g["mat3d"])).numpy(), g["iou3d"], rtol=1e-6, equal_nan=True)
+    # the product's host-side loss / metric code (pure torch, device-agnostic) against the same vectors
+    from fusiontransformer_amd.models.metric import SegIoU
+    from fusiontransformer_amd.trainer import fusion_losses
+    p2, p3 = fusion_losses(preds, label, cw, float(g["lambda_xm"]), True)
+    assert abs(p2.item() - float(g["loss_2d"])) < 1e-6 and abs(p3.item() - float(g["loss_3d"])) < 1e-6
+    m3, m2 = SegIoU(20, name="seg_iou_3d"), SegIoU(20, name="seg_iou_2d")
+    m3.update_dict(preds, {"seg_label": label}); m2.update_dict(preds, {"seg_label": label})
+    assert np.array_equal(m3.mat.numpy(), g["mat3d"]) and np.array_equal(m2.mat.numpy(), g["mat2d"])
+    np.testing.assert_allclose(m2.iou.numpy(), g["iou2d"], rtol=1e-6, equal_nan=True)
+
+
+def test_voxel_coordinates_match_reference_augment_and_scale():
+    from fusiontransformer_amd.data.synth import scale_points_to_voxels
+    g = load("voxel_coords.npz")
+    coords, valid = scale_points_to_voxels(g["points"].copy(), 20, 4096)
+    assert np.array_equal(coords, g["coords_int"]) and np.array_equal(valid, g["valid"])
+
+
+def test_projection_matches_reference_preprocess():
+    from fusiontransformer_amd.data.synth import project_points
+    g = load("projection.npz")
+    keep, pts_img = project_points(g["points"].copy(), g["proj_matrix"], 1226, 370)
+    assert np.array_equal(keep, g["keep_idx"])
+    assert np.array_equal(pts_img, g["points_img"])
+    assert np.array_equal(pts_img.astype(np.int64), g["img_indices"])
+
+
+@pytest.mark.gpu
+def test_product_lift_and_resample_match_reference_goldens():
+    """The libftx lift gather / nearest resample against the vectors produced by the reference code."""
+    from fusiontransformer_amd.models.image_models_billinear import BilinearModule
+    g = load("bilinear_lift.npz")
+    up = BilinearModule(768, 96, (370, 1226))
+    up.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("up.")})
+    up = up.cuda().train()
+    tokens = torch.from_numpy(g["tok_q"].astype(np.float32) / 32.0).cuda()
+    from fusiontransformer_amd import functional as spf
+    from fusiontransformer_amd.models.image_models_billinear import pack_img_indices
+    grid = up.forward_tokens(tokens, (24, 24))
+    idx, frame = pack_img_indices([g["idx0"], g["idx1"]], "cuda")
+    feats = spf.lift_gather(grid, idx, frame, 370, 1226).cpu().numpy()
+    np.testing.assert_allclose(feats, g["feats"], rtol=1e-4, atol=1e-5)
+    down = BilinearModule(3, 3, (384, 384))
+    down.load_state_dict({k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("down.")})
+    down = down.cuda().train()
+    out = down(torch.from_numpy(g["img_q"].astype(np.float32) / 256.0).cuda()).cpu().numpy()
+    np.testing.assert_allclose(out, g["down_out"], rtol=1e-4, atol=1e-5)

