@@ -48,19 +48,18 @@ def build_inputs(cfg, batch, shape, rank, device):
 def spconv_roofline(log):
     """Algorithmic bytes / HIP-event time over the sparse-conv launches of one timed step.
 
-    Per (in,out) pair the unit is 4*(ca+co) bytes (gather ca floats + scatter/write
-    co floats), plus the kernel weights 4*kvol*ca*co read once per launch."""
-    pair_cache = {}
+    Unit = one (in,out) pair: 4*(ca+co) bytes (gather ca floats + write co floats), plus
+    the kernel weights 4*kvol*ca*co read once per convolution.  A convolution is two launches
+    (pair gather-GEMM, ordered reduce) or one (weight gradient); the bytes are attributed to the
+    GEMM / wgrad launch, the reduce launch adds time only."""
     tot_bytes = tot_ms = tot_flops = 0.0
     per_kind = {}
-    for kind, e0, e1, tbl, m in log:
-        key = tbl.data_ptr()
-        if key not in pair_cache:
-            pair_cache[key] = int((tbl >= 0).sum().item())
-        pairs = pair_cache[key]
-        nbytes = 4.0 * pairs * (m["ca"] + m["co"]) + 4.0 * m["kvol"] * m["ca"] * m["co"]
-        flops = 2.0 * pairs * m["ca"] * m["co"]
+    for kind, e0, e1, m in log:
         ms = e0.elapsed_time(e1)
+        nbytes = flops = 0.0
+        if kind != "spconv_reduce":
+            nbytes = 4.0 * m["pairs"] * (m["ca"] + m["co"]) + 4.0 * m["kvol"] * m["ca"] * m["co"]
+            flops = 2.0 * m["pairs"] * m["ca"] * m["co"]
         tot_bytes += nbytes
         tot_ms += ms
         tot_flops += flops
@@ -72,15 +71,17 @@ def spconv_roofline(log):
     if tot_ms <= 0:
         return None
     achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
+    n_conv = sum(v[0] for k, v in per_kind.items() if k != "spconv_reduce")
     return {
-        "bound": "hbm", "kernel": "spconv_gemm_kernel+spconv_wgrad_kernel (sparse conv fwd / dgrad / wgrad)",
+        "bound": "hbm", "kernel": "pairs_gemm_kernel + spconv_reduce_kernel + pairs_wgrad_kernel (sparse conv fwd / dgrad / wgrad)",
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
         "traffic": None,
-        "launches": len(log), "avg_launch_us": round(1e3 * tot_ms / len(log), 2),
+        "launches": len(log), "convolutions": n_conv, "avg_conv_us": round(1e3 * tot_ms / max(n_conv, 1), 2),
         "algorithmic_bytes_per_step": int(tot_bytes), "useful_tflops": round(tot_flops / (tot_ms * 1e-3) / 1e12, 3),
         "mfma_f32_peak_tflops": MFMA_F32_PEAK_TFLOPS,
-        "per_kernel": {k: {"launches": v[0], "ms": round(v[1], 3), "GB/s": round(v[2] / (v[1] * 1e-3) / 1e9, 1),
-                           "useful_TFLOP/s": round(v[3] / (v[1] * 1e-3) / 1e12, 2)} for k, v in per_kind.items()},
+        "per_kernel": {k: {"launches": v[0], "ms": round(v[1], 3), "avg_us": round(1e3 * v[1] / v[0], 1),
+                           "GB/s": round(v[2] / (v[1] * 1e-3) / 1e9, 1), "useful_TFLOP/s": round(v[3] / (v[1] * 1e-3) / 1e12, 2)}
+                       for k, v in per_kind.items()},
     }
 
 

@@ -32,7 +32,9 @@ SIGNATURES = {
     "ftx_downsample_coords": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "ftx_gather_coords": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "ftx_kernel_map_build": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp, _i64, _vp, _vp]),
-    "ftx_kernel_map_transpose": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp]),
+    "ftx_kernel_map_count_workspace_bytes": (_sz, [_i64, _i32]),
+    "ftx_kernel_map_count": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "ftx_kernel_map_pairs": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     "ftx_trilinear_weights": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "ftx_voxelize_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),
     "ftx_voxelize_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),
@@ -42,9 +44,10 @@ SIGNATURES = {
     "ftx_lift_gather_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ftx_resample_nearest_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ftx_resample_nearest_bwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "ftx_spconv_gemm": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "ftx_spconv_wgrad_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
-    "ftx_spconv_wgrad": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "ftx_spconv_pairs_gemm": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "ftx_spconv_reduce": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "ftx_spconv_pairs_wgrad_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
+    "ftx_spconv_pairs_wgrad": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "ftx_bn_workspace_bytes": (_sz, [_i64, _i32]),
     "ftx_bn_train_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ftx_bn_eval_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i32, _i32, _vp, _vp]),

@@ -313,32 +313,6 @@ extern "C" int ftx_kernel_map_build(const int32_t *out_coords, int64_t n_out, co
   return check_launch("ftx_kernel_map_build");
 }
 
-__global__ void fill_i32_kernel(int32_t *__restrict__ p, int64_t n, int32_t v) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
-}
-
-__global__ void kernel_map_transpose_kernel(const int32_t *__restrict__ nbr, int64_t n_out, int64_t n_in, int k, int32_t *__restrict__ nbr_t) {
-  const int64_t total = n_out * k;
-  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    int32_t i = nbr[e];
-    if (i >= 0 && i < n_in) {
-      int kk = (int)(e / n_out);
-      int64_t o = e - (int64_t)kk * n_out;
-      nbr_t[(int64_t)kk * n_in + i] = (int32_t)o;
-    }
-  }
-}
-
-extern "C" int ftx_kernel_map_transpose(const int32_t *nbr, int64_t n_out, int64_t n_in, int32_t k, int32_t *nbr_t, void *stream) {
-  FTX_REQUIRE(n_out >= 0 && n_in >= 0 && k >= 1, "ftx_kernel_map_transpose: bad size");
-  if (n_in == 0) return FTX_OK;
-  FTX_REQUIRE(nbr_t && (nbr || n_out == 0), "ftx_kernel_map_transpose: null pointer");
-  fill_i32_kernel<<<grid_for(n_in * k, 256), 256, 0, (hipStream_t)stream>>>(nbr_t, n_in * k, -1);
-  if (n_out > 0)
-    kernel_map_transpose_kernel<<<grid_for(n_out * k, 256), 256, 0, (hipStream_t)stream>>>(nbr, n_out, n_in, k, nbr_t);
-  return check_launch("ftx_kernel_map_transpose");
-}
-
 // ---------------------------------------------------------------- trilinear weights
 // float64 arithmetic as upstream calc_ti_weights; corner order (bx,by,bz) with z fastest
 // (= KernelRegion(2, s, 1) offsets).

@@ -1,51 +1,189 @@
-// Sparse convolution on gfx950: output-stationary implicit GEMM over the kernel
-// offsets with exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
+// Sparse convolution on gfx950 as  pair-list gather-GEMM  +  ordered reduce.
 //
-//   out[r,:] = sum_k A[tbl[k,r],:] @ Wk          (ftx_spconv_gemm)
-//   dW[k]    = sum_r A[tbl[k,r],:]^T @ G[r,:]    (ftx_spconv_wgrad)
+// A kernel map is stored as ONE compacted pair list, sorted by (offset k, output row):
+//   pair_in[p], pair_out[p]            rows of the input / output tensor joined by pair p
+//   koff[k] .. koff[k+1]               the pairs of offset k
+//   pos[k, o] / pos_t[k, i]            position of the pair (k,o) / (k,i) in the list, or -1
 //
-// Every output row is owned by exactly one wave and written once: no float atomics,
-// bit-reproducible.  The neighbour table is (kvol, n_out) so a wave's 32 rows read 128
-// contiguous bytes of it per offset; the gathered rows of A are staged in LDS with 16-byte
-// loads (8 lanes cover one 128-byte row piece).
+//   forward      tmp[p]  = in[pair_in[p]]   @ W[k(p)]        out[o] = sum_k tmp[pos[k,o]]
+//   data grad    tmp[p]  = gout[pair_out[p]] @ W[k(p)]^T     gin[i] = sum_k tmp[pos_t[k,i]]
+//   weight grad  dW[k]   = sum_{p in k} in[pair_in[p]]^T @ gout[pair_out[p]]
 //
-// MFMA operand maps (cdna_hip_programming.md §3): A operand lane l holds A[i=l&31][k=l>>5],
-// B operand lane l holds B[k=l>>5][j=l&31]; accumulator reg g of lane l is
-// C[row=(g&3)+8*(g>>2)+4*(l>>5)][col=l&31].  The reduction index is free to be permuted as
-// long as A and B agree, so lane half h consumes k = 8t+4h+s for MFMA s of group t: the A
-// fragment for four MFMAs is then ONE ds_read_b128 (row stride 36 floats: conflict-free).
+// Only real (in,out) pairs reach the matrix cores (an output-stationary implicit GEMM spends
+// ~80% of its MFMAs on absent neighbours: a voxel has ~5-9 of 27), every tile of 128 pairs
+// shares one W[k], and the reduce adds each row's <= 27 partial rows in fixed k order: no float
+// atomics anywhere, results are bit-reproducible.  tmp costs one extra streamed write + read of
+// P x co floats, which is cheaper than the atomic rate (1.3 TB/s) by ~4x.
+//
+// MFMA: exact-fp32 v_mfma_f32_32x32x2_f32.  Operand maps (cdna_hip_programming.md §3): A operand
+// lane l holds A[i=l&31][k=l>>5], B operand lane l holds B[k=l>>5][j=l&31]; accumulator reg g of
+// lane l is C[row=(g&3)+8*(g>>2)+4*(l>>5)][col=l&31].  The reduction index may be permuted as
+// long as A and B agree: lane half h consumes k = 8t+4h+s for MFMA s of group t, so the A fragment
+// of four MFMAs is ONE ds_read_b128 (row stride 36 floats -> conflict-free).
+#include <cstring>
+#include <cstdlib>
 #include "ftx_common.h"
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 using namespace ftx;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;        // reduction chunk (channels of A) staged per step
-constexpr int AS_STRIDE = 36; // floats; 16-byte aligned rows, conflict-free ds_read_b128
+// ---------------------------------------------------------------------------------------
+// pair lists
+// ---------------------------------------------------------------------------------------
+struct IsValid {
+  __host__ __device__ int32_t operator()(int32_t v) const { return v >= 0 ? 1 : 0; }
+};
 
-template <int WM, int WN, int NT>
-__global__ __launch_bounds__(64 * WM * WN) void spconv_gemm_kernel(const float *__restrict__ A, int64_t rows_a,
-                                                                     const float *__restrict__ W, const int32_t *__restrict__ tbl,
-                                                                     int64_t n_out, int ca, int co, int kvol, int w_transposed,
-                                                                     float *__restrict__ out) {
-  constexpr int NTHREADS = 64 * WM * WN;
-  constexpr int BM = 32 * WM;
-  constexpr int BN = 32 * NT * WN;
+extern "C" size_t ftx_kernel_map_count_workspace_bytes(int64_t n_out, int32_t k) {
+  if (n_out <= 0 || k <= 0) return 256;
+  size_t bytes = 0;
+  const int32_t *in = nullptr;
+  int32_t *out = nullptr;
+  auto it = rocprim::make_transform_iterator(in, IsValid());
+  if (rocprim::exclusive_scan(nullptr, bytes, it, out, 0, (size_t)(n_out * k), rocprim::plus<int32_t>()) != hipSuccess) return 0;
+  return bytes + 256;
+}
+
+__global__ void koff_kernel(const int32_t *__restrict__ nbr, const int32_t *__restrict__ scan, int64_t n_out, int k, int32_t *__restrict__ koff) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < k) koff[t] = scan[(int64_t)t * n_out];
+  if (t == k) {
+    int64_t last = (int64_t)k * n_out - 1;
+    koff[k] = scan[last] + (nbr[last] >= 0 ? 1 : 0);
+  }
+}
+
+extern "C" int ftx_kernel_map_count(const int32_t *nbr, int64_t n_out, int32_t k, int32_t *pos, int32_t *koff, void *workspace,
+                                    size_t workspace_bytes, void *stream) {
+  FTX_REQUIRE(n_out >= 0 && k >= 1, "ftx_kernel_map_count: bad size");
+  FTX_REQUIRE(koff, "ftx_kernel_map_count: null koff");
+  hipStream_t st = (hipStream_t)stream;
+  if (n_out == 0) {
+    if (hipMemsetAsync(koff, 0, sizeof(int32_t) * (k + 1), st) != hipSuccess) return check_launch("ftx_kernel_map_count memset");
+    return FTX_OK;
+  }
+  FTX_REQUIRE(nbr && pos && workspace, "ftx_kernel_map_count: null pointer");
+  FTX_REQUIRE(n_out * k < 0x7fffffff, "ftx_kernel_map_count: map too large for int32 positions");
+  size_t need = ftx_kernel_map_count_workspace_bytes(n_out, k);
+  if (workspace_bytes < need) {
+    set_error("ftx_kernel_map_count: workspace %zu < required %zu", workspace_bytes, need);
+    return FTX_EWORKSPACE;
+  }
+  size_t bytes = workspace_bytes;
+  auto it = rocprim::make_transform_iterator(nbr, IsValid());
+  // pos temporarily holds the exclusive scan of the validity flags (k-major = sorted by (k, row))
+  if (rocprim::exclusive_scan(workspace, bytes, it, pos, 0, (size_t)(n_out * k), rocprim::plus<int32_t>(), st) != hipSuccess) {
+    set_error("ftx_kernel_map_count: scan failed");
+    return FTX_ELAUNCH;
+  }
+  koff_kernel<<<1, 64, 0, st>>>(nbr, pos, n_out, k, koff);
+  return check_launch("ftx_kernel_map_count");
+}
+
+__global__ void fill_m1_kernel(int32_t *__restrict__ p, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = -1;
+}
+
+__global__ void pairs_scatter_kernel(const int32_t *__restrict__ nbr, int64_t n_out, int64_t n_in, int k, int32_t *__restrict__ pos,
+                                     int32_t *__restrict__ pos_t, int32_t *__restrict__ pair_in, int32_t *__restrict__ pair_out,
+                                     int64_t cap) {
+  const int64_t total = n_out * k;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    int32_t i = nbr[e];
+    int32_t p = pos[e];
+    if (i >= 0 && i < n_in && p < cap) {
+      int kk = (int)(e / n_out);
+      int64_t o = e - (int64_t)kk * n_out;
+      pair_in[p] = i;
+      pair_out[p] = (int32_t)o;
+      pos_t[(int64_t)kk * n_in + i] = p;
+    } else {
+      pos[e] = -1;
+    }
+  }
+}
+
+extern "C" int ftx_kernel_map_pairs(const int32_t *nbr, int64_t n_out, int64_t n_in, int32_t k, int32_t *pos, int32_t *pos_t, int32_t *pair_in,
+                                    int32_t *pair_out, int64_t n_pairs, void *stream) {
+  FTX_REQUIRE(n_out >= 0 && n_in >= 0 && k >= 1 && n_pairs >= 0, "ftx_kernel_map_pairs: bad size");
+  hipStream_t st = (hipStream_t)stream;
+  if (n_in > 0) {
+    FTX_REQUIRE(pos_t, "ftx_kernel_map_pairs: null pos_t");
+    fill_m1_kernel<<<grid_for(n_in * k, 256), 256, 0, st>>>(pos_t, n_in * k);
+  }
+  if (n_out == 0) return check_launch("ftx_kernel_map_pairs");
+  FTX_REQUIRE(nbr && pos && (n_pairs == 0 || (pair_in && pair_out)), "ftx_kernel_map_pairs: null pointer");
+  pairs_scatter_kernel<<<grid_for(n_out * k, 256), 256, 0, st>>>(nbr, n_out, n_in, k, pos, pos_t, pair_in, pair_out, n_pairs);
+  return check_launch("ftx_kernel_map_pairs");
+}
+
+// ---------------------------------------------------------------------------------------
+// phase 1: tmp[p,:] = A[gather[p],:] @ Wk(p)        (tiles of 128 pairs of one offset)
+// ---------------------------------------------------------------------------------------
+constexpr int BK = 32;         // reduction chunk staged per step
+constexpr int AS_STRIDE = 36;  // floats
+constexpr int TILE_P = 128;    // pairs per tile (4 waves x 32)
+
+template <int NT>
+__global__ __launch_bounds__(256) void pairs_gemm_kernel(const float *__restrict__ A, int64_t rows_a, const int32_t *__restrict__ gather,
+                                                         const float *__restrict__ W, int w_transposed, const int32_t *__restrict__ koff,
+                                                         int ca, int co, int kvol, float *__restrict__ tmp) {
+  constexpr int BN = 32 * NT;
   constexpr int BS_STRIDE = BN + 4;
-  constexpr int ROWS_PER_PASS = NTHREADS / 8;
-  constexpr int A_PASSES = (BM + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
-  constexpr int B_VEC = BK * BN / 4;
-  constexpr int B_PASSES = (B_VEC + NTHREADS - 1) / NTHREADS;
+  constexpr int B_VEC = BK * BN / 4;           // float4 per W chunk
+  constexpr int B_PASSES = (B_VEC + 255) / 256;
 
-  __shared__ __attribute__((aligned(16))) float As[BM * AS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float As[TILE_P * AS_STRIDE];
   __shared__ __attribute__((aligned(16))) float Bs[BK * BS_STRIDE];
+  __shared__ int s_tile[3];
 
   const int tid = threadIdx.x;
+  if (tid < 64) {
+    // tile -> (offset, first pair, pair count): wave 0 scans the per-offset tile counts
+    const int lane0 = tid;
+    const int b = blockIdx.x;
+    int c = (lane0 < kvol) ? koff[lane0 + 1] - koff[lane0] : 0;
+    int nt = (c + TILE_P - 1) / TILE_P;
+    int incl = nt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      int v = __shfl_up(incl, off, 64);
+      if (lane0 >= off) incl += v;
+    }
+    int excl = incl - nt;
+    bool mine = (lane0 < kvol) && b >= excl && b < incl;
+    unsigned long long m = __ballot(mine);
+    if (mine) {
+      int t = b - excl;
+      int left = c - t * TILE_P;
+      s_tile[0] = lane0;
+      s_tile[1] = koff[lane0] + t * TILE_P;
+      s_tile[2] = left > TILE_P ? TILE_P : left;
+    }
+    if (m == 0ull && lane0 == 0) s_tile[0] = -1;
+  }
+  __syncthreads();
+  const int k = s_tile[0];
+  if (k < 0) return;  // surplus block of the upper-bound grid
+  const int p0 = s_tile[1], cnt = s_tile[2];
+
   const int wave = tid >> 6, lane = tid & 63;
-  const int wm = wave % WM, wn = wave / WM;
   const int half = lane >> 5, l31 = lane & 31;
-  const int64_t row0 = (int64_t)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
+  const int arow = tid >> 3, acol = (tid & 7) * 4;
+
+  int32_t src[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    int r = p * 32 + arow;
+    int32_t s = (r < cnt) ? gather[p0 + r] : -1;
+    if (s >= rows_a) s = -1;
+    src[p] = s;
+  }
+  const float *Wk = W + (int64_t)k * ca * co;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -53,166 +191,166 @@ __global__ __launch_bounds__(64 * WM * WN) void spconv_gemm_kernel(const float *
 #pragma unroll
     for (int g = 0; g < 16; ++g) acc[j][g] = 0.f;
 
-  const int arow = tid >> 3;        // row (within a pass) this thread gathers
-  const int acol = (tid & 7) * 4;   // first of its 4 channels within the BK chunk
-
-  for (int k = 0; k < kvol; ++k) {
-    int32_t src[A_PASSES];
-    int any = 0;
+  float4 ra[4], rb[B_PASSES];
+  auto load_chunk = [&](int c0) {
 #pragma unroll
-    for (int p = 0; p < A_PASSES; ++p) {
-      int r = p * ROWS_PER_PASS + arow;
-      int64_t gr = row0 + r;
-      int32_t s = (r < BM && gr < n_out) ? tbl[(int64_t)k * n_out + gr] : -1;
-      if (s >= rows_a) s = -1;
-      src[p] = s;
-      any |= (s >= 0);
+    for (int p = 0; p < 4; ++p) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (src[p] >= 0 && c0 + acol < ca) v = *(const float4 *)&A[(int64_t)src[p] * ca + c0 + acol];
+      ra[p] = v;
     }
-    if (!__syncthreads_or(any)) continue;  // no row of this tile has a neighbour at offset k
-
-    const float *Wk = W + (int64_t)k * ca * co;
-    for (int c0 = 0; c0 < ca; c0 += BK) {
-      // ---- stage gathered A rows (zeros for absent neighbours / channel tail)
 #pragma unroll
-      for (int p = 0; p < A_PASSES; ++p) {
-        int r = p * ROWS_PER_PASS + arow;
-        if (r < BM) {
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (src[p] >= 0 && c0 + acol < ca) v = *(const float4 *)&A[(int64_t)src[p] * ca + c0 + acol];
-          *(float4 *)&As[r * AS_STRIDE + acol] = v;
+    for (int q = 0; q < B_PASSES; ++q) {
+      int e = q * 256 + tid;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < B_VEC) {
+        if (!w_transposed) {
+          int kk = e / (BN / 4), n4 = (e - kk * (BN / 4)) * 4;
+          if (c0 + kk < ca && n0 + n4 < co) v = *(const float4 *)&Wk[(int64_t)(c0 + kk) * co + n0 + n4];
+        } else {  // W[k] stored (co, ca): 16 bytes along ca
+          int nn = e / (BK / 4), k4 = (e - nn * (BK / 4)) * 4;
+          if (n0 + nn < co && c0 + k4 < ca) v = *(const float4 *)&Wk[(int64_t)(n0 + nn) * ca + c0 + k4];
         }
       }
-      // ---- stage the W[k] chunk: Bs[kk][n] = Wk[c0+kk][n0+n]
-      if (!w_transposed) {
-#pragma unroll
-        for (int q = 0; q < B_PASSES; ++q) {
-          int e = q * NTHREADS + tid;
-          if (e < B_VEC) {
-            int kk = e / (BN / 4);
-            int n4 = (e - kk * (BN / 4)) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c0 + kk < ca && n0 + n4 < co) v = *(const float4 *)&Wk[(int64_t)(c0 + kk) * co + n0 + n4];
-            *(float4 *)&Bs[kk * BS_STRIDE + n4] = v;
-          }
-        }
-      } else {
-        // W[k] stored (co, ca): read 16 bytes along ca, scatter the 4 values down a Bs column
-#pragma unroll
-        for (int q = 0; q < B_PASSES; ++q) {
-          int e = q * NTHREADS + tid;
-          if (e < B_VEC) {
-            int nn = e / (BK / 4);
-            int k4 = (e - nn * (BK / 4)) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n0 + nn < co && c0 + k4 < ca) v = *(const float4 *)&Wk[(int64_t)(n0 + nn) * ca + c0 + k4];
-            Bs[(k4 + 0) * BS_STRIDE + nn] = v.x;
-            Bs[(k4 + 1) * BS_STRIDE + nn] = v.y;
-            Bs[(k4 + 2) * BS_STRIDE + nn] = v.z;
-            Bs[(k4 + 3) * BS_STRIDE + nn] = v.w;
-          }
-        }
-      }
-      __syncthreads();
-      // ---- MFMA over the chunk
-      const float *arow_p = &As[(wm * 32 + l31) * AS_STRIDE + 4 * half];
-      const float *bcol_p = &Bs[(4 * half) * BS_STRIDE + wn * 32 * NT + l31];
-#pragma unroll
-      for (int t = 0; t < BK / 8; ++t) {
-        float4 a = *(const float4 *)(arow_p + 8 * t);
-        float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-#pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            float b = bcol_p[(8 * t + s) * BS_STRIDE + j * 32];
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b, acc[j], 0, 0, 0);
-          }
-        }
-      }
-      __syncthreads();
+      rb[q] = v;
     }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *(float4 *)&As[(p * 32 + arow) * AS_STRIDE + acol] = ra[p];
+#pragma unroll
+    for (int q = 0; q < B_PASSES; ++q) {
+      int e = q * 256 + tid;
+      if (e < B_VEC) {
+        if (!w_transposed) {
+          int kk = e / (BN / 4), n4 = (e - kk * (BN / 4)) * 4;
+          *(float4 *)&Bs[kk * BS_STRIDE + n4] = rb[q];
+        } else {
+          int nn = e / (BK / 4), k4 = (e - nn * (BK / 4)) * 4;
+          Bs[(k4 + 0) * BS_STRIDE + nn] = rb[q].x;
+          Bs[(k4 + 1) * BS_STRIDE + nn] = rb[q].y;
+          Bs[(k4 + 2) * BS_STRIDE + nn] = rb[q].z;
+          Bs[(k4 + 3) * BS_STRIDE + nn] = rb[q].w;
+        }
+      }
+    }
+  };
+
+  load_chunk(0);
+  for (int c0 = 0; c0 < ca; c0 += BK) {
+    store_chunk();
+    __syncthreads();
+    if (c0 + BK < ca) load_chunk(c0 + BK);  // next chunk's global loads fly under the MFMAs
+    const float *arow_p = &As[(wave * 32 + l31) * AS_STRIDE + 4 * half];
+    const float *bcol_p = &Bs[(4 * half) * BS_STRIDE + l31];
+#pragma unroll
+    for (int t = 0; t < BK / 8; ++t) {
+      float4 a = *(const float4 *)(arow_p + 8 * t);
+      float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          float b = bcol_p[(8 * t + s) * BS_STRIDE + j * 32];
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b, acc[j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
   }
 
-  // ---- write the tile (each 32-lane half stores 128 contiguous bytes per register)
+  // ---- tmp rows of this tile are contiguous: each 32-lane half stores 128 bytes per register
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    int col = n0 + wn * 32 * NT + j * 32 + l31;
+    int col = n0 + j * 32 + l31;
     if (col < co) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
-        int64_t r = row0 + wm * 32 + (g & 3) + 8 * (g >> 2) + 4 * half;
-        if (r < n_out) out[r * co + col] = acc[j][g];
+        int r = wave * 32 + (g & 3) + 8 * (g >> 2) + 4 * half;
+        if (r < cnt) tmp[(int64_t)(p0 + r) * co + col] = acc[j][g];
       }
     }
   }
 }
 
-template <int WM, int WN, int NT>
-static void launch_gemm(const float *A, int64_t rows_a, const float *W, const int32_t *tbl, int64_t n_out, int ca, int co, int kvol,
-                        int wT, float *out, hipStream_t st) {
-  constexpr int BM = 32 * WM, BN = 32 * NT * WN;
-  dim3 grid((unsigned)ceil_div(n_out, BM), (unsigned)ceil_div(co, BN));
-  spconv_gemm_kernel<WM, WN, NT><<<grid, 64 * WM * WN, 0, st>>>(A, rows_a, W, tbl, n_out, ca, co, kvol, wT, out);
-}
-
-extern "C" int ftx_spconv_gemm(const float *A, int64_t rows_a, const float *W, const int32_t *tbl, int64_t n_out, int32_t ca, int32_t co,
-                               int32_t kvol, int32_t w_transposed, float *out, void *stream) {
-  FTX_REQUIRE(n_out >= 0 && rows_a >= 0 && kvol >= 1, "ftx_spconv_gemm: bad size");
-  FTX_REQUIRE(ca >= 4 && ca % 4 == 0 && co >= 4 && co % 4 == 0, "ftx_spconv_gemm: channels must be multiples of 4 (ca=%d co=%d)", ca, co);
-  if (n_out == 0) return FTX_OK;
-  FTX_REQUIRE(W && tbl && out && (A || rows_a == 0), "ftx_spconv_gemm: null pointer");
+extern "C" int ftx_spconv_pairs_gemm(const float *A, int64_t rows_a, const int32_t *gather, const float *W, int32_t w_transposed,
+                                     const int32_t *koff, int64_t n_pairs, int32_t ca, int32_t co, int32_t kvol, float *tmp, void *stream) {
+  FTX_REQUIRE(n_pairs >= 0 && rows_a >= 0 && kvol >= 1, "ftx_spconv_pairs_gemm: bad size");
+  FTX_REQUIRE(ca >= 4 && ca % 4 == 0 && co >= 4 && co % 4 == 0, "ftx_spconv_pairs_gemm: channels must be multiples of 4 (ca=%d co=%d)", ca, co);
+  if (n_pairs == 0) return FTX_OK;
+  FTX_REQUIRE(A && gather && W && koff && tmp, "ftx_spconv_pairs_gemm: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  // Tall tiles (128 rows) when the level has enough rows to fill the chip, otherwise
-  // 32-row tiles with the 4 waves spread over the output channels.
-  const int64_t tall_blocks = ceil_div(n_out, 128) * ceil_div(co, 128);
-  const bool tall = tall_blocks >= 256 || co <= 32;
-  if (tall) {
-    int nt = co >= 128 ? 4 : (co + 31) / 32;
-    if (co > 128 && co % 96 == 0 && co % 128 != 0) nt = 3;
-    switch (nt) {
-      case 1: launch_gemm<4, 1, 1>(A, rows_a, W, tbl, n_out, ca, co, kvol, w_transposed, out, st); break;
-      case 2: launch_gemm<4, 1, 2>(A, rows_a, W, tbl, n_out, ca, co, kvol, w_transposed, out, st); break;
-      case 3: launch_gemm<4, 1, 3>(A, rows_a, W, tbl, n_out, ca, co, kvol, w_transposed, out, st); break;
-      default: launch_gemm<4, 1, 4>(A, rows_a, W, tbl, n_out, ca, co, kvol, w_transposed, out, st); break;
-    }
-  } else {
-    if (co <= 128)
-      launch_gemm<1, 4, 1>(A, rows_a, W, tbl, n_out, ca, co, kvol, w_transposed, out, st);
-    else if (co % 96 == 0 && co % 128 != 0)
-      launch_gemm<1, 4, 3>(A, rows_a, W, tbl, n_out, ca, co, kvol, w_transposed, out, st);
-    else
-      launch_gemm<1, 4, 2>(A, rows_a, W, tbl, n_out, ca, co, kvol, w_transposed, out, st);
+  const unsigned tiles_ub = (unsigned)(ceil_div(n_pairs, TILE_P) + kvol);  // sum_k ceil(cnt_k/128) <= P/128 + kvol
+  int nt = co >= 128 ? 4 : (co + 31) / 32;
+  if (co > 128 && co % 96 == 0 && co % 128 != 0) nt = 3;
+  dim3 grid(tiles_ub, (unsigned)ceil_div(co, 32 * nt));
+  switch (nt) {
+    case 1: pairs_gemm_kernel<1><<<grid, 256, 0, st>>>(A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp); break;
+    case 2: pairs_gemm_kernel<2><<<grid, 256, 0, st>>>(A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp); break;
+    case 3: pairs_gemm_kernel<3><<<grid, 256, 0, st>>>(A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp); break;
+    default: pairs_gemm_kernel<4><<<grid, 256, 0, st>>>(A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp); break;
   }
-  return check_launch("ftx_spconv_gemm");
+  return check_launch("ftx_spconv_pairs_gemm");
 }
 
 // ---------------------------------------------------------------------------------------
-// Weight gradient.  Block (k, chunk, mt, nt) reduces the rows of its chunk for offset k into a
-// 128(ca) x 128(cg) tile of dW[k]; rows of the chunk WITH a neighbour at offset k are first
-// compacted (ordered, so the sum order is fixed) so the MFMAs only see real pairs.
-// Chunks are combined by a second, deterministic pass.
+// phase 2: out[r,:] = sum_k tmp[pos[k,r],:]   (fixed k order; rows without pairs become 0)
 // ---------------------------------------------------------------------------------------
-constexpr int WG_CHUNK = 1024;   // rows compacted per round
-constexpr int WG_BR = 32;        // compacted pairs staged per MFMA step
+__global__ void spconv_reduce_kernel(const float *__restrict__ tmp, const int32_t *__restrict__ pos, int64_t n, int co, int kvol,
+                                     float *__restrict__ out) {
+  const int cv = co >> 2;
+  const int64_t total = n * cv;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = e / cv;
+    int j = (int)(e - r * cv) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < kvol; ++k) {
+      int32_t p = pos[(int64_t)k * n + r];
+      if (p >= 0) {
+        float4 v = *(const float4 *)&tmp[(int64_t)p * co + j];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    *(float4 *)&out[r * co + j] = acc;
+  }
+}
+
+extern "C" int ftx_spconv_reduce(const float *tmp, const int32_t *pos, int64_t n, int32_t co, int32_t kvol, float *out, void *stream) {
+  FTX_REQUIRE(n >= 0 && kvol >= 1 && co >= 4 && co % 4 == 0, "ftx_spconv_reduce: bad size");
+  if (n == 0) return FTX_OK;
+  FTX_REQUIRE(pos && out, "ftx_spconv_reduce: null pointer");
+  int64_t work = n * (co / 4);
+  int64_t g = ceil_div(work, 256);
+  if (g > 8192) g = 8192;
+  spconv_reduce_kernel<<<(unsigned)g, 256, 0, (hipStream_t)stream>>>(tmp, pos, n, co, kvol, out);
+  return check_launch("ftx_spconv_reduce");
+}
+
+// ---------------------------------------------------------------------------------------
+// weight gradient: dW[k] = sum_{p in k} A[idx_a[p],:]^T @ G[idx_g[p],:]
+// Block (k, slice, mt, nt) reduces its slice of offset k's pairs into a 128(ca) x 128(cg) tile;
+// slices are combined by a second, ordered pass.
+// ---------------------------------------------------------------------------------------
+constexpr int WG_BR = 32;  // pairs staged per step
 constexpr int WG_TM = 128, WG_TN = 128;
 constexpr int WG_STRIDE = WG_TM + 4;
 
-__global__ __launch_bounds__(256) void spconv_wgrad_kernel(const float *__restrict__ A, int64_t rows_a, const float *__restrict__ G,
-                                                            const int32_t *__restrict__ tbl, int64_t n_rows, int ca, int cg, int kvol,
-                                                            int64_t rows_per_chunk, int nchunks, float *__restrict__ part) {
+__global__ __launch_bounds__(256) void pairs_wgrad_kernel(const float *__restrict__ A, int64_t rows_a, const int32_t *__restrict__ idx_a,
+                                                          const float *__restrict__ G, int64_t rows_g, const int32_t *__restrict__ idx_g,
+                                                          const int32_t *__restrict__ koff, int ca, int cg, int kvol, int nslices,
+                                                          float *__restrict__ part) {
   __shared__ __attribute__((aligned(16))) float As[WG_BR * WG_STRIDE];
   __shared__ __attribute__((aligned(16))) float Gs[WG_BR * WG_STRIDE];
-  __shared__ int32_t pair_a[WG_CHUNK];
-  __shared__ int32_t pair_r[WG_CHUNK];
-  __shared__ int wave_cnt[4];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int half = lane >> 5, l31 = lane & 31;
   const int k = blockIdx.x % kvol;
-  const int chunk = blockIdx.x / kvol;
+  const int slice = blockIdx.x / kvol;
   const int m0 = blockIdx.y * WG_TM, n0 = blockIdx.z * WG_TN;
-  const int64_t r_begin = (int64_t)chunk * rows_per_chunk;
-  const int64_t r_end = (r_begin + rows_per_chunk < n_rows) ? r_begin + rows_per_chunk : n_rows;
+  const int k_lo = koff[k], k_hi = koff[k + 1];
+  const int per = ((k_hi - k_lo + nslices - 1) / nslices + WG_BR - 1) / WG_BR * WG_BR;
+  const int lo = k_lo + slice * per;
+  const int hi = (lo + per < k_hi) ? lo + per : k_hi;
 
   f32x16 acc[4];
 #pragma unroll
@@ -220,61 +358,55 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(const float *__restri
 #pragma unroll
     for (int g = 0; g < 16; ++g) acc[j][g] = 0.f;
 
-  for (int64_t rb = r_begin; rb < r_end; rb += WG_CHUNK) {
-    // ---- ordered compaction of the rows of this round that have a neighbour at offset k
-    int npairs = 0;
-    for (int sub = 0; sub < WG_CHUNK; sub += 256) {
-      int64_t r = rb + sub + tid;
-      int32_t s = (r < r_end) ? tbl[(int64_t)k * n_rows + r] : -1;
-      if (s >= rows_a) s = -1;
-      unsigned long long bal = __ballot(s >= 0);
-      if (lane == 0) wave_cnt[wave] = __popcll(bal);
-      __syncthreads();
-      int base = npairs;
-      for (int w = 0; w < wave; ++w) base += wave_cnt[w];
-      int total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-      if (s >= 0) {
-        int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-        pair_a[pos] = s;
-        pair_r[pos] = (int32_t)(r - rb);
-      }
-      npairs += total;
-      __syncthreads();
+  const int pr = tid >> 3;          // this thread stages pair (pr) of the step, 4 x 16 bytes of each operand
+  const int cb = (tid & 7) * 4;
+  float4 ra[4], rg[4];
+  auto load_step = [&](int p0) {
+    int p = p0 + pr;
+    int32_t ia = -1, ig = -1;
+    if (p < hi) {
+      ia = idx_a[p];
+      ig = idx_g[p];
+      if (ia >= rows_a || ig >= rows_g) ia = ig = -1;
     }
-    // ---- MFMA over the compacted pairs, WG_BR at a time
-    for (int p0 = 0; p0 < npairs; p0 += WG_BR) {
-      // stage: 32 pairs x 128 channels for each operand = 1024 float4 each -> 4 per thread
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        int e = q * 256 + tid;
-        int pr = e >> 5;             // pair within the step
-        int c4 = (e & 31) * 4;       // channel within the tile
-        float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vg = va;
-        if (p0 + pr < npairs) {
-          if (m0 + c4 < ca) va = *(const float4 *)&A[(int64_t)pair_a[p0 + pr] * ca + m0 + c4];
-          if (n0 + c4 < cg) vg = *(const float4 *)&G[(rb + pair_r[p0 + pr]) * cg + n0 + c4];
-        }
-        *(float4 *)&As[pr * WG_STRIDE + c4] = va;
-        *(float4 *)&Gs[pr * WG_STRIDE + c4] = vg;
+    for (int q = 0; q < 4; ++q) {
+      int c4 = cb + q * 32;
+      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vg = va;
+      if (ia >= 0) {
+        if (m0 + c4 < ca) va = *(const float4 *)&A[(int64_t)ia * ca + m0 + c4];
+        if (n0 + c4 < cg) vg = *(const float4 *)&G[(int64_t)ig * cg + n0 + c4];
       }
-      __syncthreads();
-      // wave w owns channels [32w, 32w+32) of A (M) and all 128 of G (N)
-#pragma unroll
-      for (int s2 = 0; s2 < WG_BR / 2; ++s2) {
-        int kk = 2 * s2 + half;
-        float a = As[kk * WG_STRIDE + wave * 32 + l31];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float b = Gs[kk * WG_STRIDE + j * 32 + l31];
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
-        }
-      }
-      __syncthreads();
+      ra[q] = va;
+      rg[q] = vg;
     }
+  };
+
+  if (lo < hi) load_step(lo);
+  for (int p0 = lo; p0 < hi; p0 += WG_BR) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int c4 = cb + q * 32;
+      *(float4 *)&As[pr * WG_STRIDE + c4] = ra[q];
+      *(float4 *)&Gs[pr * WG_STRIDE + c4] = rg[q];
+    }
+    __syncthreads();
+    if (p0 + WG_BR < hi) load_step(p0 + WG_BR);
+    // wave w owns channels [32w, 32w+32) of A (M) and all 128 of G (N)
+#pragma unroll
+    for (int s2 = 0; s2 < WG_BR / 2; ++s2) {
+      int kk = 2 * s2 + half;
+      float a = As[kk * WG_STRIDE + wave * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float b = Gs[kk * WG_STRIDE + j * 32 + l31];
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
   }
 
-  // ---- partial tile -> part[chunk][k][ca][cg]
-  float *dst = part + ((int64_t)chunk * kvol + k) * ca * cg;
+  float *dst = part + ((int64_t)slice * kvol + k) * ca * cg;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     int col = n0 + j * 32 + l31;
@@ -288,10 +420,10 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(const float *__restri
   }
 }
 
-__global__ void wgrad_reduce_kernel(const float *__restrict__ part, int64_t elems, int nchunks, float *__restrict__ dW) {
+__global__ void wgrad_reduce_kernel(const float *__restrict__ part, int64_t elems, int nslices, float *__restrict__ dW) {
   for (int64_t e = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; e < elems; e += (int64_t)gridDim.x * blockDim.x * 4) {
     float4 s = *(const float4 *)&part[e];
-    for (int c = 1; c < nchunks; ++c) {
+    for (int c = 1; c < nslices; ++c) {
       float4 v = *(const float4 *)&part[(int64_t)c * elems + e];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
@@ -299,47 +431,48 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ part, int64_t elem
   }
 }
 
-static int wgrad_chunks(int64_t n_rows, int ca, int cg, int kvol) {
+static int wgrad_slices(int64_t n_pairs, int ca, int cg, int kvol) {
   int64_t tiles = (int64_t)kvol * ceil_div(ca, WG_TM) * ceil_div(cg, WG_TN);
-  int64_t want = ceil_div(1024, tiles);                 // aim for ~1024 blocks
-  int64_t max_chunks = ceil_div(n_rows, WG_CHUNK);      // at least one compaction round each
-  if (want > max_chunks) want = max_chunks;
+  int64_t want = ceil_div(1536, tiles);                       // ~6 blocks per CU
+  int64_t max_slices = ceil_div(ceil_div(n_pairs, kvol), 256);  // keep >= ~256 pairs per slice
+  if (want > max_slices) want = max_slices;
   if (want < 1) want = 1;
+  if (want > 64) want = 64;
   return (int)want;
 }
 
-extern "C" size_t ftx_spconv_wgrad_workspace_bytes(int64_t n_rows, int32_t ca, int32_t cg, int32_t kvol) {
-  if (n_rows <= 0 || ca <= 0 || cg <= 0 || kvol <= 0) return 256;
-  int nchunks = wgrad_chunks(n_rows, ca, cg, kvol);
-  if (nchunks <= 1) return 256;
-  return sizeof(float) * (size_t)nchunks * kvol * ca * cg;
+extern "C" size_t ftx_spconv_pairs_wgrad_workspace_bytes(int64_t n_pairs, int32_t ca, int32_t cg, int32_t kvol) {
+  if (n_pairs <= 0 || ca <= 0 || cg <= 0 || kvol <= 0) return 256;
+  int ns = wgrad_slices(n_pairs, ca, cg, kvol);
+  if (ns <= 1) return 256;
+  return sizeof(float) * (size_t)ns * kvol * ca * cg;
 }
 
-extern "C" int ftx_spconv_wgrad(const float *A, int64_t rows_a, const float *G, const int32_t *tbl, int64_t n_rows, int32_t ca,
-                                int32_t cg, int32_t kvol, float *dW, void *workspace, size_t workspace_bytes, void *stream) {
-  FTX_REQUIRE(n_rows >= 0 && rows_a >= 0 && kvol >= 1, "ftx_spconv_wgrad: bad size");
-  FTX_REQUIRE(ca >= 4 && ca % 4 == 0 && cg >= 4 && cg % 4 == 0, "ftx_spconv_wgrad: channels must be multiples of 4 (ca=%d cg=%d)", ca, cg);
-  FTX_REQUIRE(dW, "ftx_spconv_wgrad: null dW");
+extern "C" int ftx_spconv_pairs_wgrad(const float *A, int64_t rows_a, const int32_t *idx_a, const float *G, int64_t rows_g, const int32_t *idx_g,
+                                      const int32_t *koff, int64_t n_pairs, int32_t ca, int32_t cg, int32_t kvol, float *dW, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
+  FTX_REQUIRE(n_pairs >= 0 && rows_a >= 0 && rows_g >= 0 && kvol >= 1, "ftx_spconv_pairs_wgrad: bad size");
+  FTX_REQUIRE(ca >= 4 && ca % 4 == 0 && cg >= 4 && cg % 4 == 0, "ftx_spconv_pairs_wgrad: channels must be multiples of 4 (ca=%d cg=%d)", ca, cg);
+  FTX_REQUIRE(dW, "ftx_spconv_pairs_wgrad: null dW");
   hipStream_t st = (hipStream_t)stream;
   const int64_t elems = (int64_t)kvol * ca * cg;
-  if (n_rows == 0) {
-    if (hipMemsetAsync(dW, 0, sizeof(float) * elems, st) != hipSuccess) return check_launch("ftx_spconv_wgrad memset");
+  if (n_pairs == 0) {
+    if (hipMemsetAsync(dW, 0, sizeof(float) * elems, st) != hipSuccess) return check_launch("ftx_spconv_pairs_wgrad memset");
     return FTX_OK;
   }
-  FTX_REQUIRE(A && G && tbl, "ftx_spconv_wgrad: null pointer");
-  const int nchunks = wgrad_chunks(n_rows, ca, cg, kvol);
-  int64_t rows_per_chunk = ceil_div(ceil_div(n_rows, nchunks), WG_CHUNK) * WG_CHUNK;
+  FTX_REQUIRE(A && G && idx_a && idx_g && koff, "ftx_spconv_pairs_wgrad: null pointer");
+  const int ns = wgrad_slices(n_pairs, ca, cg, kvol);
   float *part = dW;
-  if (nchunks > 1) {
-    size_t need = sizeof(float) * (size_t)nchunks * elems;
+  if (ns > 1) {
+    size_t need = sizeof(float) * (size_t)ns * elems;
     if (!workspace || workspace_bytes < need) {
-      set_error("ftx_spconv_wgrad: workspace %zu < required %zu", workspace_bytes, need);
+      set_error("ftx_spconv_pairs_wgrad: workspace %zu < required %zu", workspace_bytes, need);
       return FTX_EWORKSPACE;
     }
     part = (float *)workspace;
   }
-  dim3 grid((unsigned)(kvol * nchunks), (unsigned)ceil_div(ca, WG_TM), (unsigned)ceil_div(cg, WG_TN));
-  spconv_wgrad_kernel<<<grid, 256, 0, st>>>(A, rows_a, G, tbl, n_rows, ca, cg, kvol, rows_per_chunk, nchunks, part);
-  if (nchunks > 1) wgrad_reduce_kernel<<<grid_for(elems / 4, 256), 256, 0, st>>>(part, elems, nchunks, dW);
-  return check_launch("ftx_spconv_wgrad");
+  dim3 grid((unsigned)(kvol * ns), (unsigned)ceil_div(ca, WG_TM), (unsigned)ceil_div(cg, WG_TN));
+  pairs_wgrad_kernel<<<grid, 256, 0, st>>>(A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part);
+  if (ns > 1) wgrad_reduce_kernel<<<grid_for(elems / 4, 256), 256, 0, st>>>(part, elems, ns, dW);
+  return check_launch("ftx_spconv_pairs_wgrad");
 }

@@ -142,13 +142,30 @@ def kernel_map_build(out_coords: torch.Tensor, offsets: torch.Tensor, table: Has
     return nbr
 
 
-def kernel_map_transpose(nbr: torch.Tensor, n_in: int) -> torch.Tensor:
+def kernel_map_count(nbr: torch.Tensor):
+    """Step 1 of the pair list: returns (pos scratch (K,N_out), koff (K+1,) int32 on the device).
+    koff[-1] is the number of pairs; the caller reads it back (one host sync) to size the arrays."""
     L = _lib.load()
-    req(nbr, I32, "kernel_map_transpose nbr", 2)
+    req(nbr, I32, "kernel_map_count nbr", 2)
     k, n_out = nbr.shape
-    out = _empty((k, int(n_in)), I32, nbr)
-    check(L.ftx_kernel_map_transpose(ptr(nbr), n_out, int(n_in), k, ptr(out), stream()), "ftx_kernel_map_transpose")
-    return out
+    pos = torch.empty_like(nbr)
+    koff = _empty((k + 1,), I32, nbr)
+    ws_bytes = int(L.ftx_kernel_map_count_workspace_bytes(n_out, k))
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=nbr.device)
+    check(L.ftx_kernel_map_count(ptr(nbr), n_out, k, ptr(pos), ptr(koff), ptr(ws), ws_bytes, stream()), "ftx_kernel_map_count")
+    return pos, koff
+
+
+def kernel_map_pairs(nbr: torch.Tensor, pos: torch.Tensor, n_in: int, n_pairs: int):
+    """Step 2: (pos (K,N_out), pos_t (K,N_in), pair_in (P,), pair_out (P,))."""
+    L = _lib.load()
+    k, n_out = nbr.shape
+    pos_t = _empty((k, int(n_in)), I32, nbr)
+    pair_in = _empty((int(n_pairs),), I32, nbr)
+    pair_out = _empty((int(n_pairs),), I32, nbr)
+    check(L.ftx_kernel_map_pairs(ptr(nbr), n_out, int(n_in), k, ptr(pos), ptr(pos_t), ptr(pair_in), ptr(pair_out), int(n_pairs), stream()),
+          "ftx_kernel_map_pairs")
+    return pos, pos_t, pair_in, pair_out
 
 
 def calc_ti_weights(pc: torch.Tensor, idx_query: torch.Tensor, scale: int = 1) -> torch.Tensor:
@@ -232,87 +249,98 @@ def spdevoxelize(feats, idx, weights):
 
 
 # ---------------------------------------------------------------- sparse convolution
-# When set to a list, every sparse-conv launch appends (kind, start_event, end_event, table,
+# When set to a list, every sparse-conv launch appends (kind, start_event, end_event,
 # shape dict): HIP events recorded on the launch stream, read back by bench.py after the step.
 LAUNCH_LOG = None
 
 
-def _log_launch(kind, tbl, meta, launch):
+def _log_launch(kind, meta, launch):
     if LAUNCH_LOG is None:
         return launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     out = launch()
     e1.record()
-    LAUNCH_LOG.append((kind, e0, e1, tbl, meta))
+    LAUNCH_LOG.append((kind, e0, e1, meta))
     return out
 
 
-def _spconv_gemm(A, W, tbl, n_out, co, w_transposed):
+def _spconv_apply(A, W, gather, pos, koff, n_pairs, n_rows_out, co, w_transposed):
+    """reduce(pairs_gemm(A[gather] @ W[k]), pos) -> (n_rows_out, co)."""
     L = _lib.load()
     rows_a, ca = A.shape
-    kvol = tbl.shape[0]
-    out = _empty((n_out, co), F32, A)
+    kvol = koff.shape[0] - 1
+    tmp = _empty((n_pairs, co), F32, A)
+    out = _empty((n_rows_out, co), F32, A)
 
-    def launch():
-        check(L.ftx_spconv_gemm(ptr(A), rows_a, ptr(W), ptr(tbl), n_out, ca, co, kvol, int(w_transposed), ptr(out), stream()), "ftx_spconv_gemm")
-        return out
+    def launch_gemm():
+        check(L.ftx_spconv_pairs_gemm(ptr(A), rows_a, ptr(gather), ptr(W), int(w_transposed), ptr(koff), n_pairs, ca, co, kvol, ptr(tmp), stream()),
+              "ftx_spconv_pairs_gemm")
 
-    return _log_launch("spconv_gemm", tbl, dict(n_out=n_out, ca=ca, co=co, kvol=kvol), launch)
+    def launch_reduce():
+        check(L.ftx_spconv_reduce(ptr(tmp), ptr(pos), n_rows_out, co, kvol, ptr(out), stream()), "ftx_spconv_reduce")
+
+    meta = dict(pairs=n_pairs, n_out=n_rows_out, ca=ca, co=co, kvol=kvol)
+    _log_launch("spconv_pairs_gemm", meta, launch_gemm)
+    _log_launch("spconv_reduce", meta, launch_reduce)
+    return out
 
 
-def _spconv_wgrad(A, G, tbl, kvol):
+def _spconv_wgrad(A, idx_a, G, idx_g, koff, n_pairs):
     L = _lib.load()
     rows_a, ca = A.shape
-    n_rows, cg = G.shape
+    rows_g, cg = G.shape
+    kvol = koff.shape[0] - 1
     dW = _empty((kvol, ca, cg), F32, A)
-    ws_bytes = int(L.ftx_spconv_wgrad_workspace_bytes(n_rows, ca, cg, kvol))
+    ws_bytes = int(L.ftx_spconv_pairs_wgrad_workspace_bytes(n_pairs, ca, cg, kvol))
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=A.device)
 
     def launch():
-        check(L.ftx_spconv_wgrad(ptr(A), rows_a, ptr(G), ptr(tbl), n_rows, ca, cg, kvol, ptr(dW), ptr(ws), ws_bytes, stream()), "ftx_spconv_wgrad")
-        return dW
+        check(L.ftx_spconv_pairs_wgrad(ptr(A), rows_a, ptr(idx_a), ptr(G), rows_g, ptr(idx_g), ptr(koff), n_pairs, ca, cg, kvol, ptr(dW), ptr(ws),
+                                       ws_bytes, stream()), "ftx_spconv_pairs_wgrad")
 
-    return _log_launch("spconv_wgrad", tbl, dict(n_out=n_rows, ca=ca, co=cg, kvol=kvol), launch)
+    _log_launch("spconv_pairs_wgrad", dict(pairs=n_pairs, n_out=rows_g, ca=ca, co=cg, kvol=kvol), launch)
+    return dW
 
 
 class _SparseConv(torch.autograd.Function):
-    """out[r] = sum_k feats[tbl_fwd[k,r]] @ kernel[k].
+    """out[o] = sum over pairs (k, i->o) of feats[i] @ kernel[k].
 
-    tbl_fwd (K, n_out) indexes rows of `feats`; tbl_bwd (K, n_in) is its transpose
-    (rows of grad_out).  For a strided conv tbl_fwd = nbr, tbl_bwd = nbr_t; the
-    transposed conv passes them the other way round (models/spvcnn.py:42-46)."""
+    `km` is a KernelMap (pair list); `transposed` swaps the roles of its two sides: the
+    transposed conv of models/spvcnn.py:42-46 reuses the paired strided conv's map."""
 
     @staticmethod
-    def forward(ctx, feats, kernel, tbl_fwd, tbl_bwd):
+    def forward(ctx, feats, kernel, km, transposed):
         feats = req(feats.contiguous(), F32, "conv3d feats", 2)
         kernel = req(kernel.contiguous(), F32, "conv3d kernel", 3)
-        req(tbl_fwd, I32, "conv3d tbl_fwd", 2)
-        req(tbl_bwd, I32, "conv3d tbl_bwd", 2)
         kvol, ca, co = kernel.shape
-        if feats.shape[1] != ca or tbl_fwd.shape[0] != kvol or tbl_bwd.shape[0] != kvol:
-            raise ValueError(f"conv3d: shape mismatch feats {tuple(feats.shape)} kernel {tuple(kernel.shape)} tbl {tuple(tbl_fwd.shape)}")
-        if tbl_bwd.shape[1] != feats.shape[0]:
-            raise ValueError("conv3d: transposed table does not match the input rows")
-        out = _spconv_gemm(feats, kernel, tbl_fwd, tbl_fwd.shape[1], co, 0)
-        ctx.save_for_backward(feats, kernel, tbl_fwd, tbl_bwd)
+        n_in, n_out = (km.n_out, km.n_in) if transposed else (km.n_in, km.n_out)
+        if feats.shape != (n_in, ca) or km.kvol != kvol:
+            raise ValueError(f"conv3d: shape mismatch feats {tuple(feats.shape)} kernel {tuple(kernel.shape)} map ({km.kvol},{n_in}->{n_out})")
+        gather, pos = (km.pair_out, km.pos_t) if transposed else (km.pair_in, km.pos)
+        out = _spconv_apply(feats, kernel, gather, pos, km.koff, km.n_pairs, n_out, co, 0)
+        ctx.save_for_backward(feats, kernel)
+        ctx.km, ctx.transposed = km, transposed
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        feats, kernel, tbl_fwd, tbl_bwd = ctx.saved_tensors
+        feats, kernel = ctx.saved_tensors
+        km, transposed = ctx.km, ctx.transposed
         grad_out = req(grad_out.contiguous(), F32, "conv3d grad", 2)
         kvol, ca, co = kernel.shape
         g_feats = g_kernel = None
+        in_side, out_side = (km.pair_out, km.pair_in) if transposed else (km.pair_in, km.pair_out)
         if ctx.needs_input_grad[0]:
-            g_feats = _spconv_gemm(grad_out, kernel, tbl_bwd, feats.shape[0], ca, 1)
+            pos_in = km.pos if transposed else km.pos_t
+            g_feats = _spconv_apply(grad_out, kernel, out_side, pos_in, km.koff, km.n_pairs, feats.shape[0], ca, 1)
         if ctx.needs_input_grad[1]:
-            g_kernel = _spconv_wgrad(feats, grad_out, tbl_fwd, kvol)
+            g_kernel = _spconv_wgrad(feats, in_side, grad_out, out_side, km.koff, km.n_pairs)
         return g_feats, g_kernel, None, None
 
 
-def sparse_conv(feats, kernel, tbl_fwd, tbl_bwd):
-    return _SparseConv.apply(feats, kernel, tbl_fwd, tbl_bwd)
+def sparse_conv(feats, kernel, km, transposed=False):
+    return _SparseConv.apply(feats, kernel, km, transposed)
 
 
 # ---------------------------------------------------------------- BatchNorm (+residual)(+ReLU)

@@ -48,14 +48,14 @@ class Conv3d(nn.Module):
             return out
         if not self.t:
             km = x.cm.kernel_map(ks, x.s, s)
-            feats = spf.sparse_conv(x.F, self.kernel, km.nbr, km.nbr_t)
+            feats = spf.sparse_conv(x.F, self.kernel, km, False)
             out = x.derive(feats, km.out_coords, x.s * s)
         else:
             original_stride = x.s // s
             km = x.cm.kernel_maps.get((ks, original_stride, s))
             if km is None:
                 raise RuntimeError("transposed Conv3d needs the kernel map of the paired strided Conv3d")
-            feats = spf.sparse_conv(x.F, self.kernel, km.nbr_t, km.nbr)
+            feats = spf.sparse_conv(x.F, self.kernel, km, True)
             out = x.derive(feats, x.cm.coords[original_stride], original_stride)
         out.check()
         return out

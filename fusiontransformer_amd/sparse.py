@@ -9,8 +9,9 @@ model code touches (`.F`, `.C`, `.s`, `.coord_maps`, `.kernel_maps`,
 Data layout in HBM: voxel features are row-major (N, C) float32; coordinates
 (N, 4) int32 [x, y, z, batch]; a kernel map is two dense neighbour tables
 (K, N_out) and (K, N_in) int32 with -1 for "no neighbour", K-major so that a
-wave's 32 output rows read 128 contiguous bytes per offset.  Row order of every
-level is ascending coordinate hash (= upstream's torch.unique order)."""
+wave's 32 output rows read 128 contiguous bytes per offset; the convolutions run
+on its compacted pair list (pair_in / pair_out / koff, pos / pos_t).  Row order of
+every level is ascending coordinate hash (= upstream's torch.unique order)."""
 from __future__ import annotations
 
 import numpy as np
@@ -20,10 +21,12 @@ from . import functional as Fn
 
 
 class KernelMap:
-    __slots__ = ("nbr", "nbr_t", "n_in", "n_out", "out_coords", "kvol")
+    """Pair list of one (kernel size, input stride, stride) map: see csrc/ftx_spconv.hip."""
+    __slots__ = ("nbr", "pos", "pos_t", "pair_in", "pair_out", "koff", "n_pairs", "n_in", "n_out", "out_coords", "kvol")
 
-    def __init__(self, nbr, nbr_t, n_in, n_out, out_coords):
-        self.nbr, self.nbr_t, self.n_in, self.n_out, self.out_coords = nbr, nbr_t, n_in, n_out, out_coords
+    def __init__(self, nbr, pos, pos_t, pair_in, pair_out, koff, n_pairs, n_in, n_out, out_coords):
+        self.nbr, self.pos, self.pos_t, self.pair_in, self.pair_out, self.koff = nbr, pos, pos_t, pair_in, pair_out, koff
+        self.n_pairs, self.n_in, self.n_out, self.out_coords = n_pairs, n_in, n_out, out_coords
         self.kvol = nbr.shape[0]
 
 
@@ -71,8 +74,12 @@ class CoordinateManager:
                 out_coords = Fn.gather_coords(down, first[:n_out].contiguous())
                 self.coords[new_stride] = out_coords
         nbr = Fn.kernel_map_build(out_coords, off, table)
-        nbr_t = Fn.kernel_map_transpose(nbr, n_in)
-        km = KernelMap(nbr, nbr_t, n_in, out_coords.shape[0], out_coords)
+        pos, koff = Fn.kernel_map_count(nbr)
+        # a strided kernel-2 map joins every input voxel to exactly one (parent, offset): P = N_in;
+        # for the submanifold maps the pair count is data dependent (one host sync)
+        n_pairs = n_in if (ks == stride and ks == 2) else int(koff[-1].item())
+        pos, pos_t, pair_in, pair_out = Fn.kernel_map_pairs(nbr, pos, n_in, n_pairs)
+        km = KernelMap(nbr, pos, pos_t, pair_in, pair_out, koff, n_pairs, n_in, out_coords.shape[0], out_coords)
         self.kernel_maps[key] = km
         return km
 

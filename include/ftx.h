@@ -80,8 +80,16 @@ int ftx_gather_coords(const int32_t *src, const int32_t *index, int64_t n, int32
 /* nbr[k, o] = row in the table's key set of (out_coords[o] + offsets[k]), or -1.
  * Fuses sphash(out_coords, offsets) + sphashquery.  nbr is (k, n_out) int32. */
 int ftx_kernel_map_build(const int32_t *out_coords, int64_t n_out, const int32_t *offsets, int32_t k, const int64_t *table_keys, const int32_t *table_vals, int64_t capacity, int32_t *nbr, void *stream);
-/* nbr_t[k, i] = o where nbr[k, o] == i, else -1.  nbr_t is (k, n_in) int32, fully written. */
-int ftx_kernel_map_transpose(const int32_t *nbr, int64_t n_out, int64_t n_in, int32_t k, int32_t *nbr_t, void *stream);
+/* Pair list of a kernel map (what torchsparse's convert_neighbor_map builds): the valid
+ * (k, o) entries of nbr compacted in (k, o) order.
+ *   step 1  ftx_kernel_map_count: pos (k, n_out) receives the exclusive scan of the validity
+ *           flags, koff (k+1, device) the first pair of every offset; koff[k] = number of pairs
+ *           (the caller reads it back to size the pair arrays).
+ *   step 2  ftx_kernel_map_pairs: pair_in[p] / pair_out[p] = input / output row of pair p;
+ *           pos[k,o] = p or -1; pos_t (k, n_in): pos_t[k, i] = p of the pair (k, i) or -1. */
+size_t ftx_kernel_map_count_workspace_bytes(int64_t n_out, int32_t k);
+int ftx_kernel_map_count(const int32_t *nbr, int64_t n_out, int32_t k, int32_t *pos, int32_t *koff, void *workspace, size_t workspace_bytes, void *stream);
+int ftx_kernel_map_pairs(const int32_t *nbr, int64_t n_out, int64_t n_in, int32_t k, int32_t *pos, int32_t *pos_t, int32_t *pair_in, int32_t *pair_out, int64_t n_pairs, void *stream);
 
 /* spf.calc_ti_weights: models/utils.py:81-82.  pc (n,4) float32 (integer-valued or not),
  * idx (n,8) int32 (point-major, as after the transpose at utils.py:83), weights (n,8) float32. */
@@ -116,22 +124,24 @@ int ftx_lift_gather_bwd(const float *grad_out, const int64_t *img_idx, const int
 int ftx_resample_nearest_fwd(const float *in, int32_t b, int32_t c, int32_t ih, int32_t iw, int32_t oh, int32_t ow, float *out, void *stream);
 int ftx_resample_nearest_bwd(const float *grad_out, int32_t b, int32_t c, int32_t ih, int32_t iw, int32_t oh, int32_t ow, float *grad_in, void *stream);
 
-/* ---- sparse convolution (spnn.Conv3d fwd/bwd) ---------------------------- */
+/* ---- sparse convolution (spnn.Conv3d fwd/bwd) ----------------------------
+ * Pair-list gather-GEMM + ordered reduce (exact-fp32 MFMA, no float atomics, bit-reproducible):
+ *   forward       tmp = pairs_gemm(A=in,   gather=pair_in,  W, 0);  out = reduce(tmp, pos,   n_out)
+ *   data grad     tmp = pairs_gemm(A=gout, gather=pair_out, W, 1);  gin = reduce(tmp, pos_t, n_in)
+ *   weight grad   dW  = pairs_wgrad(A=in, pair_in, G=gout, pair_out)
+ *   transposed conv (models/spvcnn.py:42-46): the same three calls with in/out roles swapped. */
 
-/* out[r,:] = sum_k A[tbl[k,r],:] @ Wk, rows with tbl<0 contribute nothing.
- *   A   (rows_a, ca) float32        tbl (kvol, n_out) int32 rows of A
- *   W   (kvol, ca, co) row-major when w_transposed == 0  (Wk = W[k])
- *       (kvol, co, ca) row-major when w_transposed == 1  (Wk = W[k]^T)
- *   out (n_out, co), fully written (no atomics, deterministic).
- * forward conv: A=in, tbl=nbr, W=kernel; data gradient: A=grad_out, tbl=nbr_t,
- * w_transposed=1; transposed conv swaps the two tables. */
-int ftx_spconv_gemm(const float *A, int64_t rows_a, const float *W, const int32_t *tbl, int64_t n_out, int32_t ca, int32_t co, int32_t kvol, int32_t w_transposed, float *out, void *stream);
+/* tmp[p,:] = A[gather[p],:] @ Wk(p), k(p) from koff.  A (rows_a, ca); gather (n_pairs) int32;
+ * W (kvol, ca, co) row-major when w_transposed == 0, (kvol, co, ca) used as W[k]^T when 1;
+ * koff (kvol+1) int32 DEVICE; tmp (n_pairs, co) fully written. */
+int ftx_spconv_pairs_gemm(const float *A, int64_t rows_a, const int32_t *gather, const float *W, int32_t w_transposed, const int32_t *koff, int64_t n_pairs, int32_t ca, int32_t co, int32_t kvol, float *tmp, void *stream);
 
-/* dW[k] = sum_r A[tbl[k,r],:]^T @ G[r,:]   -> dW (kvol, ca, cg), fully written.
- *   A (rows_a, ca), G (n_rows, cg), tbl (kvol, n_rows).
- * workspace: ftx_spconv_wgrad_workspace_bytes(n_rows, ca, cg, kvol). */
-size_t ftx_spconv_wgrad_workspace_bytes(int64_t n_rows, int32_t ca, int32_t cg, int32_t kvol);
-int ftx_spconv_wgrad(const float *A, int64_t rows_a, const float *G, const int32_t *tbl, int64_t n_rows, int32_t ca, int32_t cg, int32_t kvol, float *dW, void *workspace, size_t workspace_bytes, void *stream);
+/* out[r,:] = sum over k (ascending) of tmp[pos[k,r],:] for pos >= 0; out (n, co) fully written. */
+int ftx_spconv_reduce(const float *tmp, const int32_t *pos, int64_t n, int32_t co, int32_t kvol, float *out, void *stream);
+
+/* dW[k] = sum_{p in offset k} A[idx_a[p],:]^T @ G[idx_g[p],:]  -> dW (kvol, ca, cg), fully written. */
+size_t ftx_spconv_pairs_wgrad_workspace_bytes(int64_t n_pairs, int32_t ca, int32_t cg, int32_t kvol);
+int ftx_spconv_pairs_wgrad(const float *A, int64_t rows_a, const int32_t *idx_a, const float *G, int64_t rows_g, const int32_t *idx_g, const int32_t *koff, int64_t n_pairs, int32_t ca, int32_t cg, int32_t kvol, float *dW, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- BatchNorm1d over rows (+residual, +ReLU): spnn.BatchNorm / nn.BatchNorm1d
  *      models/spvcnn.py:30-31,71-79,100-102,164-180; models/middle_fusion.py:18-22 */

@@ -34,7 +34,7 @@ def test_argument_errors_are_reported_not_thrown(ftx_lib):
     assert ftx_lib.ftx_hash(None, -1, None, None) == -1
     assert b"n < 0" in ftx_lib.ftx_last_error()
     assert ftx_lib.ftx_hash(None, 0, None, None) == 0          # empty input is a no-op, not an error
-    assert ftx_lib.ftx_spconv_gemm(None, 0, None, None, 8, 6, 8, 27, 0, None, None) == -1   # channels not multiple of 4
+    assert ftx_lib.ftx_spconv_pairs_gemm(None, 0, None, None, 0, None, 8, 6, 8, 27, None, None) == -1   # channels not multiple of 4
     assert b"multiples of 4" in ftx_lib.ftx_last_error()
     assert ftx_lib.ftx_hashtable_build(None, 0, None, None, 100, None) == -1               # capacity not a power of two
     assert ftx_lib.ftx_lift_gather_fwd(None, None, None, 4, 1, 24, 24, 95, 370, 1226, None, None) == -1

@@ -98,10 +98,10 @@ def test_product_lift_and_resample_match_reference_goldens():
     from fusiontransformer_amd.models.image_models_billinear import pack_img_indices
     grid = up.forward_tokens(tokens, (24, 24))
     idx, frame = pack_img_indices([g["idx0"], g["idx1"]], "cuda")
-    feats = spf.lift_gather(grid, idx, frame, 370, 1226).cpu().numpy()
+    feats = spf.lift_gather(grid, idx, frame, 370, 1226).detach().cpu().numpy()
     np.testing.assert_allclose(feats, g["feats"], rtol=1e-4, atol=1e-5)
     down = BilinearModule(3, 3, (384, 384))
     down.load_state_dict({k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("down.")})
     down = down.cuda().train()
-    out = down(torch.from_numpy(g["img_q"].astype(np.float32) / 256.0).cuda()).cpu().numpy()
+    out = down(torch.from_numpy(g["img_q"].astype(np.float32) / 256.0).cuda()).detach().cpu().numpy()
     np.testing.assert_allclose(out, g["down_out"], rtol=1e-4, atol=1e-5)

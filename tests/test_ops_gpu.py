@@ -79,13 +79,16 @@ def test_kernel_maps_bit_exact(env):
         ref_idx, ref_out = O.build_kernel_map(ref_in, cur, ks, s)
         assert np.array_equal(km.out_coords.cpu().numpy(), ref_out), (ks, cur, s)
         assert np.array_equal(km.nbr.cpu().numpy().astype(np.int64), ref_idx), (ks, cur, s)
+        # pair list: the valid (k, o) entries in (k, o) order, and its two position tables
         nbr = km.nbr.cpu().numpy()
-        nbr_t = km.nbr_t.cpu().numpy()
-        ref_t = np.full_like(nbr_t, -1)
-        for k in range(nbr.shape[0]):
-            o = np.nonzero(nbr[k] >= 0)[0]
-            ref_t[k, nbr[k, o]] = o
-        assert np.array_equal(nbr_t, ref_t)
+        kk, oo = np.nonzero(nbr >= 0)
+        assert km.n_pairs == len(kk)
+        assert np.array_equal(km.pair_out.cpu().numpy(), oo) and np.array_equal(km.pair_in.cpu().numpy(), nbr[kk, oo])
+        koff = km.koff.cpu().numpy()
+        assert np.array_equal(koff, np.concatenate([[0], np.cumsum((nbr >= 0).sum(1))]))
+        ref_pos = np.full(nbr.shape, -1, np.int32); ref_pos[kk, oo] = np.arange(len(kk))
+        ref_pos_t = np.full((nbr.shape[0], km.n_in), -1, np.int32); ref_pos_t[kk, nbr[kk, oo]] = np.arange(len(kk))
+        assert np.array_equal(km.pos.cpu().numpy(), ref_pos) and np.array_equal(km.pos_t.cpu().numpy(), ref_pos_t)
 
 
 def test_trilinear_weights_and_floor(env):
@@ -159,7 +162,7 @@ def test_sparse_conv_fwd_bwd(env, ca, co, ks, cur, s):
     xo, wo = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(w).requires_grad_(True)
     xg, wg = dev(x).requires_grad_(True), dev(w).requires_grad_(True)
     yo = O.sparseconv_op(xo, wo, idx_query, km.n_out, False)
-    yg = spf.sparse_conv(xg, wg, km.nbr, km.nbr_t)
+    yg = spf.sparse_conv(xg, wg, km, False)
     np.testing.assert_allclose(yg.detach().cpu().numpy(), yo.detach().numpy(), rtol=1e-4, atol=2e-5)
     go = rng.standard_normal(yo.shape).astype(np.float32)
     yo.backward(torch.from_numpy(go)); yg.backward(dev(go))
@@ -171,7 +174,7 @@ def test_sparse_conv_fwd_bwd(env, ca, co, ks, cur, s):
         xco, wto = torch.from_numpy(xc).requires_grad_(True), torch.from_numpy(wt).requires_grad_(True)
         xcg, wtg = dev(xc).requires_grad_(True), dev(wt).requires_grad_(True)
         fo = O.sparseconv_op(xco, wto, idx_query, n_in, True)
-        fg = spf.sparse_conv(xcg, wtg, km.nbr_t, km.nbr)
+        fg = spf.sparse_conv(xcg, wtg, km, True)
         np.testing.assert_allclose(fg.detach().cpu().numpy(), fo.detach().numpy(), rtol=1e-4, atol=2e-5)
         g = rng.standard_normal(fo.shape).astype(np.float32)
         fo.backward(torch.from_numpy(g)); fg.backward(dev(g))
@@ -192,7 +195,7 @@ def test_sparse_conv_is_deterministic(env):
     outs = []
     for _ in range(2):
         x.grad = w.grad = None
-        y = spf.sparse_conv(x, w, km.nbr, km.nbr_t)
+        y = spf.sparse_conv(x, w, km, False)
         y.sum().backward()
         outs.append((y.detach().clone(), x.grad.clone(), w.grad.clone()))
     for a, b in zip(*outs):
@@ -273,4 +276,6 @@ def test_bad_arguments_fail_loudly(env):
         spf.sphash(torch.zeros((4, 3), dtype=torch.int32, device="cuda"))
     with pytest.raises(RuntimeError):
         x = torch.zeros((8, 6), device="cuda")  # channels not a multiple of 4
-        spf._spconv_gemm(x, torch.zeros((27, 6, 8), device="cuda"), torch.zeros((27, 8), dtype=torch.int32, device="cuda"), 8, 8, 0)
+        z = torch.zeros((8,), dtype=torch.int32, device="cuda")
+        spf._spconv_apply(x, torch.zeros((27, 6, 8), device="cuda"), z, torch.zeros((27, 8), dtype=torch.int32, device="cuda"),
+                          torch.zeros((28,), dtype=torch.int32, device="cuda"), 8, 8, 8, 0)
