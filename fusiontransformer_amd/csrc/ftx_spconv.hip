@@ -296,6 +296,7 @@ extern "C" int ftx_spconv_pairs_gemm(const float *A, int64_t rows_a, const int32
 // ---------------------------------------------------------------------------------------
 // phase 2: out[r,:] = sum_k tmp[pos[k,r],:]   (fixed k order; rows without pairs become 0)
 // ---------------------------------------------------------------------------------------
+template <int KVOL>
 __global__ void spconv_reduce_kernel(const float *__restrict__ tmp, const int32_t *__restrict__ pos, int64_t n, int co, int kvol,
                                      float *__restrict__ out) {
   const int cv = co >> 2;
@@ -304,11 +305,24 @@ __global__ void spconv_reduce_kernel(const float *__restrict__ tmp, const int32_
     int64_t r = e / cv;
     int j = (int)(e - r * cv) * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < kvol; ++k) {
-      int32_t p = pos[(int64_t)k * n + r];
-      if (p >= 0) {
-        float4 v = *(const float4 *)&tmp[(int64_t)p * co + j];
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    if (KVOL > 0) {
+      int32_t p[KVOL > 0 ? KVOL : 1];
+#pragma unroll
+      for (int k = 0; k < KVOL; ++k) p[k] = pos[(int64_t)k * n + r];
+#pragma unroll
+      for (int k = 0; k < KVOL; ++k) {
+        if (p[k] >= 0) {
+          float4 v = *(const float4 *)&tmp[(int64_t)p[k] * co + j];
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+      }
+    } else {
+      for (int k = 0; k < kvol; ++k) {
+        int32_t q = pos[(int64_t)k * n + r];
+        if (q >= 0) {
+          float4 v = *(const float4 *)&tmp[(int64_t)q * co + j];
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
       }
     }
     *(float4 *)&out[r * co + j] = acc;
@@ -322,7 +336,13 @@ extern "C" int ftx_spconv_reduce(const float *tmp, const int32_t *pos, int64_t n
   int64_t work = n * (co / 4);
   int64_t g = ceil_div(work, 256);
   if (g > 8192) g = 8192;
-  spconv_reduce_kernel<<<(unsigned)g, 256, 0, (hipStream_t)stream>>>(tmp, pos, n, co, kvol, out);
+  hipStream_t st = (hipStream_t)stream;
+  if (kvol == 27)
+    spconv_reduce_kernel<27><<<(unsigned)g, 256, 0, st>>>(tmp, pos, n, co, kvol, out);
+  else if (kvol == 8)
+    spconv_reduce_kernel<8><<<(unsigned)g, 256, 0, st>>>(tmp, pos, n, co, kvol, out);
+  else
+    spconv_reduce_kernel<0><<<(unsigned)g, 256, 0, st>>>(tmp, pos, n, co, kvol, out);
   return check_launch("ftx_spconv_reduce");
 }
 
@@ -331,90 +351,141 @@ extern "C" int ftx_spconv_reduce(const float *tmp, const int32_t *pos, int64_t n
 // Block (k, slice, mt, nt) reduces its slice of offset k's pairs into a 128(ca) x 128(cg) tile;
 // slices are combined by a second, ordered pass.
 // ---------------------------------------------------------------------------------------
-constexpr int WG_BR = 32;  // pairs staged per step
-constexpr int WG_TM = 128, WG_TN = 128;
-constexpr int WG_STRIDE = WG_TM + 4;
+constexpr int WG_BR = 32;      // pairs staged per step
+constexpr int WG_ROUND = 1024;  // pair indices kept in LDS at a time
 
+// Tile = 32*WM channels of A (M) x 32*NT channels of G (N).  With WM < 4 the spare waves split
+// the pairs of each step (KS = 4/WM ways) and are summed through LDS at the end, so narrow
+// layers (32/64 channels, the levels with the most pairs) still keep all four SIMDs busy.
+template <int WM, int NT>
 __global__ __launch_bounds__(256) void pairs_wgrad_kernel(const float *__restrict__ A, int64_t rows_a, const int32_t *__restrict__ idx_a,
                                                           const float *__restrict__ G, int64_t rows_g, const int32_t *__restrict__ idx_g,
                                                           const int32_t *__restrict__ koff, int ca, int cg, int kvol, int nslices,
                                                           float *__restrict__ part) {
-  __shared__ __attribute__((aligned(16))) float As[WG_BR * WG_STRIDE];
-  __shared__ __attribute__((aligned(16))) float Gs[WG_BR * WG_STRIDE];
+  constexpr int TM = 32 * WM, TN = 32 * NT, KS = 4 / WM;
+  constexpr int ASTR = TM + 4, GSTR = TN + 4;
+  constexpr int RED = KS > 1 ? WM * NT * 1024 : 1;
+  __shared__ __attribute__((aligned(16))) float As[WG_BR * ASTR];
+  __shared__ __attribute__((aligned(16))) float Gs[WG_BR * GSTR];
+  __shared__ float red[RED];
+  __shared__ int32_t s_ia[WG_ROUND], s_ig[WG_ROUND];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave % WM, ks = wave / WM;
   const int k = blockIdx.x % kvol;
   const int slice = blockIdx.x / kvol;
-  const int m0 = blockIdx.y * WG_TM, n0 = blockIdx.z * WG_TN;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.z * TN;
   const int k_lo = koff[k], k_hi = koff[k + 1];
   const int per = ((k_hi - k_lo + nslices - 1) / nslices + WG_BR - 1) / WG_BR * WG_BR;
   const int lo = k_lo + slice * per;
   const int hi = (lo + per < k_hi) ? lo + per : k_hi;
 
-  f32x16 acc[4];
+  f32x16 acc[NT];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int g = 0; g < 16; ++g) acc[j][g] = 0.f;
 
-  const int pr = tid >> 3;          // this thread stages pair (pr) of the step, 4 x 16 bytes of each operand
-  const int cb = (tid & 7) * 4;
-  float4 ra[4], rg[4];
+  float4 ra[WM], rg[NT];
+  int rbase = lo;  // first pair of the round whose indices are in LDS
   auto load_step = [&](int p0) {
-    int p = p0 + pr;
-    int32_t ia = -1, ig = -1;
-    if (p < hi) {
-      ia = idx_a[p];
-      ig = idx_g[p];
-      if (ia >= rows_a || ig >= rows_g) ia = ig = -1;
+#pragma unroll
+    for (int q = 0; q < WM; ++q) {
+      int e = q * 256 + tid;
+      int pr = e / (TM / 4), c4 = (e - pr * (TM / 4)) * 4;
+      int p = p0 + pr;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p < hi && p - rbase < WG_ROUND && m0 + c4 < ca) {
+        int32_t ia = s_ia[p - rbase];
+        if (ia >= 0) v = *(const float4 *)&A[(int64_t)ia * ca + m0 + c4];
+      }
+      ra[q] = v;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      int c4 = cb + q * 32;
-      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vg = va;
-      if (ia >= 0) {
-        if (m0 + c4 < ca) va = *(const float4 *)&A[(int64_t)ia * ca + m0 + c4];
-        if (n0 + c4 < cg) vg = *(const float4 *)&G[(int64_t)ig * cg + n0 + c4];
+    for (int q = 0; q < NT; ++q) {
+      int e = q * 256 + tid;
+      int pr = e / (TN / 4), c4 = (e - pr * (TN / 4)) * 4;
+      int p = p0 + pr;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p < hi && p - rbase < WG_ROUND && n0 + c4 < cg) {
+        int32_t ig = s_ig[p - rbase];
+        if (ig >= 0) v = *(const float4 *)&G[(int64_t)ig * cg + n0 + c4];
       }
-      ra[q] = va;
-      rg[q] = vg;
+      rg[q] = v;
     }
   };
 
-  if (lo < hi) load_step(lo);
-  for (int p0 = lo; p0 < hi; p0 += WG_BR) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      int c4 = cb + q * 32;
-      *(float4 *)&As[pr * WG_STRIDE + c4] = ra[q];
-      *(float4 *)&Gs[pr * WG_STRIDE + c4] = rg[q];
+  for (rbase = lo; rbase < hi; rbase += WG_ROUND) {
+    const int rend = (rbase + WG_ROUND < hi) ? rbase + WG_ROUND : hi;
+    __syncthreads();  // previous round's gathers are done with s_ia / s_ig
+    for (int t = tid; t < rend - rbase; t += 256) {
+      int32_t ia = idx_a[rbase + t], ig = idx_g[rbase + t];
+      if (ia < 0 || ia >= rows_a || ig < 0 || ig >= rows_g) ia = ig = -1;
+      s_ia[t] = ia;
+      s_ig[t] = ig;
     }
     __syncthreads();
-    if (p0 + WG_BR < hi) load_step(p0 + WG_BR);
-    // wave w owns channels [32w, 32w+32) of A (M) and all 128 of G (N)
+    load_step(rbase);
+    for (int p0 = rbase; p0 < rend; p0 += WG_BR) {
 #pragma unroll
-    for (int s2 = 0; s2 < WG_BR / 2; ++s2) {
-      int kk = 2 * s2 + half;
-      float a = As[kk * WG_STRIDE + wave * 32 + l31];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float b = Gs[kk * WG_STRIDE + j * 32 + l31];
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+      for (int q = 0; q < WM; ++q) {
+        int e = q * 256 + tid;
+        int pr = e / (TM / 4), c4 = (e - pr * (TM / 4)) * 4;
+        *(float4 *)&As[pr * ASTR + c4] = ra[q];
       }
+#pragma unroll
+      for (int q = 0; q < NT; ++q) {
+        int e = q * 256 + tid;
+        int pr = e / (TN / 4), c4 = (e - pr * (TN / 4)) * 4;
+        *(float4 *)&Gs[pr * GSTR + c4] = rg[q];
+      }
+      __syncthreads();
+      if (p0 + WG_BR < rend) load_step(p0 + WG_BR);
+#pragma unroll
+      for (int it = 0; it < WG_BR / 2 / KS; ++it) {
+        int kk = 2 * (it * KS + ks) + half;
+        float a = As[kk * ASTR + wm * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          float b = Gs[kk * GSTR + j * 32 + l31];
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
 
-  float *dst = part + ((int64_t)slice * kvol + k) * ca * cg;
+  if (KS > 1) {  // sum the pair-subsets of the KS wave groups, fixed order
+    for (int r = 1; r < KS; ++r) {
+      if (ks == r) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int col = n0 + j * 32 + l31;
-    if (col < cg) {
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        int row = m0 + wave * 32 + (g & 3) + 8 * (g >> 2) + 4 * half;
-        if (row < ca) dst[(int64_t)row * cg + col] = acc[j][g];
+          for (int g = 0; g < 16; ++g) red[((wm * NT + j) * 16 + g) * 64 + lane] = acc[j][g];
+      }
+      __syncthreads();
+      if (ks == 0) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int g = 0; g < 16; ++g) acc[j][g] += red[((wm * NT + j) * 16 + g) * 64 + lane];
+      }
+      __syncthreads();
+    }
+  }
+
+  if (ks == 0) {
+    float *dst = part + ((int64_t)slice * kvol + k) * ca * cg;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      int col = n0 + j * 32 + l31;
+      if (col < cg) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          int row = m0 + wm * 32 + (g & 3) + 8 * (g >> 2) + 4 * half;
+          if (row < ca) dst[(int64_t)row * cg + col] = acc[j][g];
+        }
       }
     }
   }
@@ -431,9 +502,18 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ part, int64_t elem
   }
 }
 
+static void wgrad_config(int ca, int cg, int *wm, int *nt) {
+  *wm = ca <= 32 ? 1 : (ca <= 64 ? 2 : 4);
+  int n = cg >= 128 ? 4 : (cg + 31) / 32;
+  if (cg > 128 && cg % 96 == 0 && cg % 128 != 0) n = 3;
+  *nt = n;
+}
+
 static int wgrad_slices(int64_t n_pairs, int ca, int cg, int kvol) {
-  int64_t tiles = (int64_t)kvol * ceil_div(ca, WG_TM) * ceil_div(cg, WG_TN);
-  int64_t want = ceil_div(1536, tiles);                       // ~6 blocks per CU
+  int wm, nt;
+  wgrad_config(ca, cg, &wm, &nt);
+  int64_t tiles = (int64_t)kvol * ceil_div(ca, 32 * wm) * ceil_div(cg, 32 * nt);
+  int64_t want = ceil_div(1536, tiles);                         // ~6 blocks per CU
   int64_t max_slices = ceil_div(ceil_div(n_pairs, kvol), 256);  // keep >= ~256 pairs per slice
   if (want > max_slices) want = max_slices;
   if (want < 1) want = 1;
@@ -446,6 +526,17 @@ extern "C" size_t ftx_spconv_pairs_wgrad_workspace_bytes(int64_t n_pairs, int32_
   int ns = wgrad_slices(n_pairs, ca, cg, kvol);
   if (ns <= 1) return 256;
   return sizeof(float) * (size_t)ns * kvol * ca * cg;
+}
+
+template <int WM>
+static void launch_wgrad(int nt, dim3 grid, hipStream_t st, const float *A, int64_t rows_a, const int32_t *idx_a, const float *G, int64_t rows_g,
+                         const int32_t *idx_g, const int32_t *koff, int ca, int cg, int kvol, int ns, float *part) {
+  switch (nt) {
+    case 1: pairs_wgrad_kernel<WM, 1><<<grid, 256, 0, st>>>(A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part); break;
+    case 2: pairs_wgrad_kernel<WM, 2><<<grid, 256, 0, st>>>(A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part); break;
+    case 3: pairs_wgrad_kernel<WM, 3><<<grid, 256, 0, st>>>(A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part); break;
+    default: pairs_wgrad_kernel<WM, 4><<<grid, 256, 0, st>>>(A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part); break;
+  }
 }
 
 extern "C" int ftx_spconv_pairs_wgrad(const float *A, int64_t rows_a, const int32_t *idx_a, const float *G, int64_t rows_g, const int32_t *idx_g,
@@ -471,8 +562,15 @@ extern "C" int ftx_spconv_pairs_wgrad(const float *A, int64_t rows_a, const int3
     }
     part = (float *)workspace;
   }
-  dim3 grid((unsigned)(kvol * ns), (unsigned)ceil_div(ca, WG_TM), (unsigned)ceil_div(cg, WG_TN));
-  pairs_wgrad_kernel<<<grid, 256, 0, st>>>(A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part);
+  int wm, nt;
+  wgrad_config(ca, cg, &wm, &nt);
+  dim3 grid((unsigned)(kvol * ns), (unsigned)ceil_div(ca, 32 * wm), (unsigned)ceil_div(cg, 32 * nt));
+  if (wm == 1)
+    launch_wgrad<1>(nt, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part);
+  else if (wm == 2)
+    launch_wgrad<2>(nt, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part);
+  else
+    launch_wgrad<4>(nt, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part);
   if (ns > 1) wgrad_reduce_kernel<<<grid_for(elems / 4, 256), 256, 0, st>>>(part, elems, ns, dW);
   return check_launch("ftx_spconv_pairs_wgrad");
 }

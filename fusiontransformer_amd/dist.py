@@ -104,6 +104,7 @@ class GradReducer:
             self._rebuilt = True
         for b in self.buckets:
             b.pending, b.work, b.launched = len(b.params), None, False
+            b.flat.zero_()   # zero_grad for every gradient of the bucket in one fill
         self.next_to_launch = 0
         self._record = self.step_idx == 0
         if self._record:

@@ -34,7 +34,10 @@ def fusion_losses(preds, seg_label, class_weights, lambda_xm, dual_head):
 def build_optimizer(cfg, model):
     """common/solver/build.py:7-20: getattr(torch.optim, TYPE)(params, lr, weight_decay)."""
     params = [p for p in model.parameters() if p.requires_grad]
-    return getattr(torch.optim, cfg.OPTIMIZER.TYPE)(params, lr=cfg.OPTIMIZER.BASE_LR, weight_decay=cfg.OPTIMIZER.WEIGHT_DECAY)
+    kwargs = dict(lr=cfg.OPTIMIZER.BASE_LR, weight_decay=cfg.OPTIMIZER.WEIGHT_DECAY)
+    if cfg.OPTIMIZER.TYPE in ("Adam", "AdamW") and params and params[0].is_cuda:
+        kwargs["fused"] = True  # same update rule, one multi-tensor kernel instead of ~10 passes over 108 M parameters
+    return getattr(torch.optim, cfg.OPTIMIZER.TYPE)(params, **kwargs)
 
 
 class TrainStep:
@@ -51,9 +54,10 @@ class TrainStep:
         self.last = {}
 
     def __call__(self, data_batch):
-        self.optimizer.zero_grad(set_to_none=False)
         if self.grad_reducer is not None:
-            self.grad_reducer.begin_step()
+            self.grad_reducer.begin_step()   # zeroes the flat gradient buckets (p.grad are views into them)
+        else:
+            self.optimizer.zero_grad(set_to_none=True)    # first write of each gradient is a move, not fill + add
         preds = self.model(data_batch)
         loss_2d, loss_3d = fusion_losses(preds, data_batch["seg_label"], self.class_weights, self.lambda_xm, self.dual_head)
         with torch.no_grad():

@@ -38,9 +38,6 @@ def _worker(rank, world, port, q):
     for step in range(4):
         torch.manual_seed(1000 + 10 * step + rank)
         x = torch.randn(5, 8)
-        for p in model.parameters():
-            if p.grad is not None:
-                p.grad.zero_()
         twin.zero_grad()
         twin(x).pow(2).sum().backward()
         local = [p.grad.detach().clone() for p in twin.parameters()]
