@@ -130,7 +130,9 @@ constexpr int TILE_P = 128;    // pairs per tile (4 waves x 32)
 template <int NT>
 __global__ __launch_bounds__(256) void pairs_gemm_kernel(const float *__restrict__ A, int64_t rows_a, const int32_t *__restrict__ gather,
                                                          const float *__restrict__ W, int w_transposed, const int32_t *__restrict__ koff,
-                                                         int ca, int co, int kvol, float *__restrict__ tmp) {
+                                                         int ca, int co, int kvol, float *__restrict__ tmp, const float *__restrict__ bias,
+                                                         int64_t n_dense) {
+  // gather == nullptr: dense mode, tmp[r,:] = A[r,:] @ W (+ bias) for r < n_dense (kvol = 1)
   constexpr int BN = 32 * NT;
   constexpr int BS_STRIDE = BN + 4;
   constexpr int B_VEC = BK * BN / 4;           // float4 per W chunk
@@ -141,7 +143,14 @@ __global__ __launch_bounds__(256) void pairs_gemm_kernel(const float *__restrict
   __shared__ int s_tile[3];
 
   const int tid = threadIdx.x;
-  if (tid < 64) {
+  if (gather == nullptr) {
+    if (tid == 0) {
+      int64_t left = n_dense - (int64_t)blockIdx.x * TILE_P;
+      s_tile[0] = left > 0 ? 0 : -1;
+      s_tile[1] = blockIdx.x * TILE_P;
+      s_tile[2] = left > TILE_P ? TILE_P : (int)left;
+    }
+  } else if (tid < 64) {
     // tile -> (offset, first pair, pair count): wave 0 scans the per-offset tile counts
     const int lane0 = tid;
     const int b = blockIdx.x;
@@ -179,7 +188,8 @@ __global__ __launch_bounds__(256) void pairs_gemm_kernel(const float *__restrict
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     int r = p * 32 + arow;
-    int32_t s = (r < cnt) ? gather[p0 + r] : -1;
+    int32_t s = -1;
+    if (r < cnt) s = gather ? gather[p0 + r] : p0 + r;
     if (s >= rows_a) s = -1;
     src[p] = s;
   }
@@ -264,10 +274,11 @@ __global__ __launch_bounds__(256) void pairs_gemm_kernel(const float *__restrict
   for (int j = 0; j < NT; ++j) {
     int col = n0 + j * 32 + l31;
     if (col < co) {
+      const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         int r = wave * 32 + (g & 3) + 8 * (g >> 2) + 4 * half;
-        if (r < cnt) tmp[(int64_t)(p0 + r) * co + col] = acc[j][g];
+        if (r < cnt) tmp[(int64_t)(p0 + r) * co + col] = acc[j][g] + bv;
       }
     }
   }
@@ -285,12 +296,34 @@ extern "C" int ftx_spconv_pairs_gemm(const float *A, int64_t rows_a, const int32
   if (co > 128 && co % 96 == 0 && co % 128 != 0) nt = 3;
   dim3 grid(tiles_ub, (unsigned)ceil_div(co, 32 * nt));
   switch (nt) {
-    case 1: pairs_gemm_kernel<1><<<grid, 256, 0, st>>>(A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp); break;
-    case 2: pairs_gemm_kernel<2><<<grid, 256, 0, st>>>(A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp); break;
-    case 3: pairs_gemm_kernel<3><<<grid, 256, 0, st>>>(A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp); break;
-    default: pairs_gemm_kernel<4><<<grid, 256, 0, st>>>(A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp); break;
+    case 1: pairs_gemm_kernel<1><<<grid, 256, 0, st>>>(A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0); break;
+    case 2: pairs_gemm_kernel<2><<<grid, 256, 0, st>>>(A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0); break;
+    case 3: pairs_gemm_kernel<3><<<grid, 256, 0, st>>>(A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0); break;
+    default: pairs_gemm_kernel<4><<<grid, 256, 0, st>>>(A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0); break;
   }
   return check_launch("ftx_spconv_pairs_gemm");
+}
+
+// Dense rows: out[r,:] = A[r,:] @ W (+ bias) on the same tile code (identity gather, one "offset").
+// The point-branch Linear layers, the 1x1x1 convolutions and the heads are skinny GEMMs
+// (81k rows x 20..256 columns, K = 32..256) that are HBM-bound: rows in, rows out, W from L2.
+extern "C" int ftx_rows_gemm(const float *A, int64_t n, const float *W, int32_t w_transposed, const float *bias, int32_t ca, int32_t co,
+                             float *out, void *stream) {
+  FTX_REQUIRE(n >= 0, "ftx_rows_gemm: n < 0");
+  FTX_REQUIRE(ca >= 4 && ca % 4 == 0 && co >= 4 && co % 4 == 0, "ftx_rows_gemm: channels must be multiples of 4 (ca=%d co=%d)", ca, co);
+  if (n == 0) return FTX_OK;
+  FTX_REQUIRE(A && W && out, "ftx_rows_gemm: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  int nt = co >= 128 ? 4 : (co + 31) / 32;
+  if (co > 128 && co % 96 == 0 && co % 128 != 0) nt = 3;
+  dim3 grid((unsigned)ceil_div(n, TILE_P), (unsigned)ceil_div(co, 32 * nt));
+  switch (nt) {
+    case 1: pairs_gemm_kernel<1><<<grid, 256, 0, st>>>(A, n, nullptr, W, w_transposed, nullptr, ca, co, 1, out, bias, n); break;
+    case 2: pairs_gemm_kernel<2><<<grid, 256, 0, st>>>(A, n, nullptr, W, w_transposed, nullptr, ca, co, 1, out, bias, n); break;
+    case 3: pairs_gemm_kernel<3><<<grid, 256, 0, st>>>(A, n, nullptr, W, w_transposed, nullptr, ca, co, 1, out, bias, n); break;
+    default: pairs_gemm_kernel<4><<<grid, 256, 0, st>>>(A, n, nullptr, W, w_transposed, nullptr, ca, co, 1, out, bias, n); break;
+  }
+  return check_launch("ftx_rows_gemm");
 }
 
 // ---------------------------------------------------------------------------------------
@@ -361,7 +394,8 @@ template <int WM, int NT>
 __global__ __launch_bounds__(256) void pairs_wgrad_kernel(const float *__restrict__ A, int64_t rows_a, const int32_t *__restrict__ idx_a,
                                                           const float *__restrict__ G, int64_t rows_g, const int32_t *__restrict__ idx_g,
                                                           const int32_t *__restrict__ koff, int ca, int cg, int kvol, int nslices,
-                                                          float *__restrict__ part) {
+                                                          float *__restrict__ part, int n_dense) {
+  // idx_a == nullptr: dense mode, rows [0, n_dense) of A and G pair up one to one (kvol = 1)
   constexpr int TM = 32 * WM, TN = 32 * NT, KS = 4 / WM;
   constexpr int ASTR = TM + 4, GSTR = TN + 4;
   constexpr int RED = KS > 1 ? WM * NT * 1024 : 1;
@@ -376,7 +410,7 @@ __global__ __launch_bounds__(256) void pairs_wgrad_kernel(const float *__restric
   const int k = blockIdx.x % kvol;
   const int slice = blockIdx.x / kvol;
   const int m0 = blockIdx.y * TM, n0 = blockIdx.z * TN;
-  const int k_lo = koff[k], k_hi = koff[k + 1];
+  const int k_lo = koff ? koff[k] : 0, k_hi = koff ? koff[k + 1] : n_dense;
   const int per = ((k_hi - k_lo + nslices - 1) / nslices + WG_BR - 1) / WG_BR * WG_BR;
   const int lo = k_lo + slice * per;
   const int hi = (lo + per < k_hi) ? lo + per : k_hi;
@@ -420,7 +454,7 @@ __global__ __launch_bounds__(256) void pairs_wgrad_kernel(const float *__restric
     const int rend = (rbase + WG_ROUND < hi) ? rbase + WG_ROUND : hi;
     __syncthreads();  // previous round's gathers are done with s_ia / s_ig
     for (int t = tid; t < rend - rbase; t += 256) {
-      int32_t ia = idx_a[rbase + t], ig = idx_g[rbase + t];
+      int32_t ia = idx_a ? idx_a[rbase + t] : rbase + t, ig = idx_g ? idx_g[rbase + t] : rbase + t;
       if (ia < 0 || ia >= rows_a || ig < 0 || ig >= rows_g) ia = ig = -1;
       s_ia[t] = ia;
       s_ig[t] = ig;
@@ -530,12 +564,12 @@ extern "C" size_t ftx_spconv_pairs_wgrad_workspace_bytes(int64_t n_pairs, int32_
 
 template <int WM>
 static void launch_wgrad(int nt, dim3 grid, hipStream_t st, const float *A, int64_t rows_a, const int32_t *idx_a, const float *G, int64_t rows_g,
-                         const int32_t *idx_g, const int32_t *koff, int ca, int cg, int kvol, int ns, float *part) {
+                         const int32_t *idx_g, const int32_t *koff, int ca, int cg, int kvol, int ns, float *part, int n_dense) {
   switch (nt) {
-    case 1: pairs_wgrad_kernel<WM, 1><<<grid, 256, 0, st>>>(A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part); break;
-    case 2: pairs_wgrad_kernel<WM, 2><<<grid, 256, 0, st>>>(A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part); break;
-    case 3: pairs_wgrad_kernel<WM, 3><<<grid, 256, 0, st>>>(A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part); break;
-    default: pairs_wgrad_kernel<WM, 4><<<grid, 256, 0, st>>>(A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part); break;
+    case 1: pairs_wgrad_kernel<WM, 1><<<grid, 256, 0, st>>>(A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part, n_dense); break;
+    case 2: pairs_wgrad_kernel<WM, 2><<<grid, 256, 0, st>>>(A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part, n_dense); break;
+    case 3: pairs_wgrad_kernel<WM, 3><<<grid, 256, 0, st>>>(A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part, n_dense); break;
+    default: pairs_wgrad_kernel<WM, 4><<<grid, 256, 0, st>>>(A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part, n_dense); break;
   }
 }
 
@@ -551,7 +585,10 @@ extern "C" int ftx_spconv_pairs_wgrad(const float *A, int64_t rows_a, const int3
     if (hipMemsetAsync(dW, 0, sizeof(float) * elems, st) != hipSuccess) return check_launch("ftx_spconv_pairs_wgrad memset");
     return FTX_OK;
   }
-  FTX_REQUIRE(A && G && idx_a && idx_g && koff, "ftx_spconv_pairs_wgrad: null pointer");
+  FTX_REQUIRE(A && G, "ftx_spconv_pairs_wgrad: null pointer");
+  const bool dense = (idx_a == nullptr && idx_g == nullptr && koff == nullptr);
+  FTX_REQUIRE(dense || (idx_a && idx_g && koff), "ftx_spconv_pairs_wgrad: idx_a, idx_g and koff must be all set or all null (dense rows)");
+  FTX_REQUIRE(!dense || (kvol == 1 && n_pairs <= rows_a && n_pairs <= rows_g && n_pairs < 0x7fffffff), "ftx_spconv_pairs_wgrad: dense mode needs kvol == 1 and n_pairs rows in A and G");
   const int ns = wgrad_slices(n_pairs, ca, cg, kvol);
   float *part = dW;
   if (ns > 1) {
@@ -566,11 +603,11 @@ extern "C" int ftx_spconv_pairs_wgrad(const float *A, int64_t rows_a, const int3
   wgrad_config(ca, cg, &wm, &nt);
   dim3 grid((unsigned)(kvol * ns), (unsigned)ceil_div(ca, 32 * wm), (unsigned)ceil_div(cg, 32 * nt));
   if (wm == 1)
-    launch_wgrad<1>(nt, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part);
+    launch_wgrad<1>(nt, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part, (int)n_pairs);
   else if (wm == 2)
-    launch_wgrad<2>(nt, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part);
+    launch_wgrad<2>(nt, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part, (int)n_pairs);
   else
-    launch_wgrad<4>(nt, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part);
+    launch_wgrad<4>(nt, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part, (int)n_pairs);
   if (ns > 1) wgrad_reduce_kernel<<<grid_for(elems / 4, 256), 256, 0, st>>>(part, elems, ns, dW);
   return check_launch("ftx_spconv_pairs_wgrad");
 }

@@ -343,6 +343,92 @@ def sparse_conv(feats, kernel, km, transposed=False):
     return _SparseConv.apply(feats, kernel, km, transposed)
 
 
+# ---------------------------------------------------------------- dense rows (skinny GEMMs)
+def _rows_gemm(A, W, w_transposed, bias, co):
+    L = _lib.load()
+    n, ca = A.shape
+    out = _empty((n, co), F32, A)
+    check(L.ftx_rows_gemm(ptr(A), n, ptr(W), int(w_transposed), ptr(bias), ca, co, ptr(out), stream()), "ftx_rows_gemm")
+    return out
+
+
+def _rows_wgrad(A, G):
+    """A (n, ca)^T @ G (n, cg) -> (ca, cg)."""
+    L = _lib.load()
+    n, ca = A.shape
+    cg = G.shape[1]
+    dW = _empty((1, ca, cg), F32, A)
+    ws_bytes = int(L.ftx_spconv_pairs_wgrad_workspace_bytes(n, ca, cg, 1))
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=A.device)
+    check(L.ftx_spconv_pairs_wgrad(ptr(A), n, 0, ptr(G), n, 0, 0, n, ca, cg, 1, ptr(dW), ptr(ws), ws_bytes, stream()), "ftx_spconv_pairs_wgrad(dense)")
+    return dW[0]
+
+
+def _rows_ok(*channels):
+    return all(c >= 4 and c % 4 == 0 for c in channels)
+
+
+class _RowsLinear(torch.autograd.Function):
+    """F.linear on (N, C) rows: out = x @ weight^T + bias, weight (co, ca) as nn.Linear stores it."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = req(x.contiguous(), F32, "linear x", 2)
+        weight = req(weight.contiguous(), F32, "linear weight", 2)
+        co, ca = weight.shape
+        if x.shape[1] != ca:
+            raise ValueError("linear: shape mismatch")
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return _rows_gemm(x, weight, 1, bias, co)
+
+    @staticmethod
+    def backward(ctx, go):
+        x, weight = ctx.saved_tensors
+        go = req(go.contiguous(), F32, "linear grad", 2)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _rows_gemm(go, weight, 0, None, weight.shape[1])
+        if ctx.needs_input_grad[1]:
+            gw = _rows_wgrad(go, x)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = go.sum(0)
+        return gx, gw, gb
+
+
+class _RowsMatmul(torch.autograd.Function):
+    """x (N, ca) @ kernel (ca, co): the kernel_size = 1 spnn.Conv3d."""
+
+    @staticmethod
+    def forward(ctx, x, kernel):
+        x = req(x.contiguous(), F32, "matmul x", 2)
+        kernel = req(kernel.contiguous(), F32, "matmul kernel", 2)
+        ctx.save_for_backward(x, kernel)
+        return _rows_gemm(x, kernel, 0, None, kernel.shape[1])
+
+    @staticmethod
+    def backward(ctx, go):
+        x, kernel = ctx.saved_tensors
+        go = req(go.contiguous(), F32, "matmul grad", 2)
+        gx = _rows_gemm(go, kernel, 1, None, kernel.shape[0]) if ctx.needs_input_grad[0] else None
+        gk = _rows_wgrad(x, go) if ctx.needs_input_grad[1] else None
+        return gx, gk
+
+
+def linear(x, weight, bias=None):
+    """nn.Linear on point / voxel rows.  Skinny shapes (tens of thousands of rows, <= 384 channels)
+    run on libftx's tile kernel; anything else is a plain library GEMM."""
+    if x.dim() == 2 and _rows_ok(x.shape[1], weight.shape[0]) and max(weight.shape) <= 512:
+        return _RowsLinear.apply(x, weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)
+
+
+def rows_matmul(x, kernel):
+    if x.dim() == 2 and _rows_ok(*kernel.shape) and max(kernel.shape) <= 512:
+        return _RowsMatmul.apply(x, kernel)
+    return torch.matmul(x, kernel)
+
+
 # ---------------------------------------------------------------- BatchNorm (+residual)(+ReLU)
 class _BatchNormTrain(torch.autograd.Function):
     @staticmethod

@@ -3,6 +3,8 @@ from __future__ import annotations
 
 import torch.nn as nn
 
+from .. import functional as spf
+
 from .image_models_billinear import Net2DBillinear
 
 
@@ -14,9 +16,9 @@ def heads(module, in_channels, num_classes, dual_head):
 
 
 def lidar_preds(module, feats):
-    preds = {"lidar_feats": feats, "lidar_seg_logit": module.linear(feats)}
+    preds = {"lidar_feats": feats, "lidar_seg_logit": spf.linear(feats, module.linear.weight, module.linear.bias)}
     if module.dual_head:
-        preds["lidar_seg_logit2"] = module.linear2(feats)
+        preds["lidar_seg_logit2"] = spf.linear(feats, module.linear2.weight, module.linear2.bias)
     return preds
 
 

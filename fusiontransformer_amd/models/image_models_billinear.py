@@ -142,10 +142,10 @@ class Net2DBillinear(nn.Module):
         x = self.sample_down(img)
         backbone_output = self.backbone.forward_blocks(x)
         late_feats = self.get_img_feats(img_indices, self.late_feat_block_number, img.shape, backbone_output)
-        x = self.linear(late_feats)
+        x = spf.linear(late_feats, self.linear.weight, self.linear.bias)
         preds = {"img_feats": late_feats, "img_seg_logit": x}
         if self.dual_head:
-            preds["img_seg_logit2"] = self.linear2(late_feats)
+            preds["img_seg_logit2"] = spf.linear(late_feats, self.linear2.weight, self.linear2.bias)
         if self.middle_feat_block_number:
             preds["img_middle_feats"] = self.get_img_feats(img_indices, self.middle_feat_block_number, img.shape, backbone_output)
         return preds

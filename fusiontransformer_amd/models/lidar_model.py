@@ -1,6 +1,8 @@
 """LidarSeg: mirror of FusionTransformer/models/lidar_model.py:4-21."""
 import torch.nn as nn
 
+from .. import functional as spf
+
 from .spvcnn import SPVCNN
 
 
@@ -12,4 +14,4 @@ class LidarSeg(nn.Module):
 
     def forward(self, data_dict):
         feats = self.backbone(data_dict["lidar"])
-        return {"lidar_seg_logit": self.linear(feats)}
+        return {"lidar_seg_logit": spf.linear(feats, self.linear.weight, self.linear.bias)}

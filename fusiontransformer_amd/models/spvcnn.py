@@ -43,7 +43,7 @@ class Conv3d(nn.Module):
     def forward(self, x: SparseTensor) -> SparseTensor:
         ks, s = self.kernel_size, self.stride
         if ks == 1 and s == 1:
-            out = x.derive(torch.matmul(x.F, self.kernel))
+            out = x.derive(spf.rows_matmul(x.F, self.kernel))
             out.check()
             return out
         if not self.t:
@@ -92,7 +92,7 @@ def _conv_bn(conv, bn, x, residual=None, relu=True):
 
 def _linear_bn_relu(seq, feats):
     """nn.Sequential(Linear, BatchNorm1d, ReLU) on point rows (spvcnn.py:164-180)."""
-    return seq[1].fused(F.linear(feats, seq[0].weight, seq[0].bias), relu=True)
+    return seq[1].fused(spf.linear(feats, seq[0].weight, seq[0].bias), relu=True)
 
 
 class BasicConvolutionBlock(nn.Module):

@@ -136,10 +136,16 @@ int ftx_resample_nearest_bwd(const float *grad_out, int32_t b, int32_t c, int32_
  * koff (kvol+1) int32 DEVICE; tmp (n_pairs, co) fully written. */
 int ftx_spconv_pairs_gemm(const float *A, int64_t rows_a, const int32_t *gather, const float *W, int32_t w_transposed, const int32_t *koff, int64_t n_pairs, int32_t ca, int32_t co, int32_t kvol, float *tmp, void *stream);
 
+/* Dense rows on the same tile code: out[r,:] = A[r,:] @ W (+ bias), r < n.  W as above with kvol = 1;
+ * bias (co) may be NULL.  Replaces the point-branch nn.Linear layers (models/spvcnn.py:164-180,
+ * models/middle_fusion.py:18-29) and the kernel_size=1 spnn.Conv3d (spvcnn.py:71-75). */
+int ftx_rows_gemm(const float *A, int64_t n, const float *W, int32_t w_transposed, const float *bias, int32_t ca, int32_t co, float *out, void *stream);
+
 /* out[r,:] = sum over k (ascending) of tmp[pos[k,r],:] for pos >= 0; out (n, co) fully written. */
 int ftx_spconv_reduce(const float *tmp, const int32_t *pos, int64_t n, int32_t co, int32_t kvol, float *out, void *stream);
 
-/* dW[k] = sum_{p in offset k} A[idx_a[p],:]^T @ G[idx_g[p],:]  -> dW (kvol, ca, cg), fully written. */
+/* dW[k] = sum_{p in offset k} A[idx_a[p],:]^T @ G[idx_g[p],:]  -> dW (kvol, ca, cg), fully written.
+ * idx_a = idx_g = koff = NULL with kvol = 1: dense rows, dW = A[:n_pairs]^T @ G[:n_pairs]. */
 size_t ftx_spconv_pairs_wgrad_workspace_bytes(int64_t n_pairs, int32_t ca, int32_t cg, int32_t kvol);
 int ftx_spconv_pairs_wgrad(const float *A, int64_t rows_a, const int32_t *idx_a, const float *G, int64_t rows_g, const int32_t *idx_g, const int32_t *koff, int64_t n_pairs, int32_t ca, int32_t cg, int32_t kvol, float *dW, void *workspace, size_t workspace_bytes, void *stream);
 

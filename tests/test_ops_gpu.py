@@ -182,6 +182,39 @@ def test_sparse_conv_fwd_bwd(env, ca, co, ks, cur, s):
         np.testing.assert_allclose(wtg.grad.cpu().numpy(), wto.grad.numpy(), rtol=1e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("n,ca,co", [(5000, 32, 256), (3001, 256, 128), (777, 96, 20), (4096, 128, 96), (130, 4, 32), (1, 384, 256)])
+def test_rows_linear_and_matmul_match_torch(env, n, ca, co):
+    spf, O = env
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((n, ca)).astype(np.float32)
+    w = (rng.standard_normal((co, ca)) / np.sqrt(ca)).astype(np.float32)
+    b = rng.standard_normal(co).astype(np.float32)
+    g = rng.standard_normal((n, co)).astype(np.float32)
+    xo, wo, bo = (torch.from_numpy(t).requires_grad_(True) for t in (x, w, b))
+    yo = torch.nn.functional.linear(xo, wo, bo)
+    yo.backward(torch.from_numpy(g))
+    xg, wg, bg = (dev(t).requires_grad_(True) for t in (x, w, b))
+    yg = spf.linear(xg, wg, bg)
+    assert yg.grad_fn is not None and "RowsLinear" in type(yg.grad_fn).__name__
+    yg.backward(dev(g))
+    np.testing.assert_allclose(yg.detach().cpu().numpy(), yo.detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xo.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(wg.grad.cpu().numpy(), wo.grad.numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(bg.grad.cpu().numpy(), bo.grad.numpy(), rtol=1e-4, atol=1e-3)
+    # kernel_size = 1 convolution: x @ kernel
+    k = np.ascontiguousarray(w.T)
+    ko = torch.from_numpy(k).requires_grad_(True)
+    xo2 = torch.from_numpy(x).requires_grad_(True)
+    zo = xo2 @ ko
+    zo.backward(torch.from_numpy(g))
+    kg, xg2 = dev(k).requires_grad_(True), dev(x).requires_grad_(True)
+    zg = spf.rows_matmul(xg2, kg)
+    zg.backward(dev(g))
+    np.testing.assert_allclose(zg.detach().cpu().numpy(), zo.detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(xg2.grad.cpu().numpy(), xo2.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(kg.grad.cpu().numpy(), ko.grad.numpy(), rtol=1e-3, atol=1e-3)
+
+
 def test_sparse_conv_is_deterministic(env):
     spf, O = env
     from fusiontransformer_amd.sparse import CoordinateManager
