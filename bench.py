@@ -146,7 +146,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="frames per GPU per step")
     ap.add_argument("--shape", default="kitti", choices=["kitti", "nuscenes"])
     ap.add_argument("--kind", default="middle", choices=["middle", "early", "late"])
-    ap.add_argument("--attn", default=os.environ.get("FTX_ATTN", "torch"))
+    ap.add_argument("--attn", default=os.environ.get("FTX_ATTN", "ftx"), choices=["ftx", "torch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

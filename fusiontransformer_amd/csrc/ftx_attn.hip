@@ -1,0 +1,389 @@
+// ViT self-attention (timm Attention.forward, reached at models/transformers.py:36-37):
+//   out = softmax(Q K^T * scale) V     per (batch, head), T tokens (578), head dim 64, fp32.
+// Flash-style: the T x T score matrix is never written.  Exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// Layout trick (cdna_hip_programming.md "accumulator tile as the next MFMA's operand"): a 32x32
+// accumulator has its COLUMN on the lane and 16 ROWS in registers (row(g,h) = (g&3)+8(g>>2)+4h,
+// h = lane>>5).  A following MFMA that sums over the tile's ROW index can take it as the B operand
+// with no lane movement.  So each product is oriented so that the index summed next is the row:
+//   forward   S^T[key][q] = K Q^T      -> softmax state per lane (one q per lane)
+//             O^T[dv][q] += V^T P^T    (sums over keys = rows of P^T)
+//   dK/dV     S[q][key]   = Q K^T,  dP[q][key] = dO V^T
+//             dV^T[dv][key] += dO^T P, dK^T[d][key] += Q^T dS      (sum over q = rows)
+//   dQ        S^T, dP^T as in the forward orientation;  dQ^T[d][q] += K^T dS^T  (sum over keys)
+// The reduction index of the first products is permuted (lane half h takes d = 8t+4h+s) so operand
+// fragments are one ds_read_b128 / one 16-byte global load per 4 MFMAs.
+#include "ftx_common.h"
+
+using namespace ftx;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int HD = 64;          // head dim (fixed)
+constexpr int TS = 68;          // LDS row stride in floats (16-byte aligned, conflict-free b128)
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+__device__ inline int acc_row(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
+
+// qkv (b, t, 3, nh, 64): row of tensor `which` (0 q, 1 k, 2 v) for token t, head hd
+__device__ inline const float *qkv_row(const float *qkv, int b, int t, int which, int hd, int T, int nh) {
+  return qkv + ((((int64_t)b * T + t) * 3 + which) * nh + hd) * HD;
+}
+
+// Load this lane's permuted 32-float fragment of a 64-float row: elements 8t+4h+s.
+__device__ inline void load_frag(const float *row, int h, bool valid, float (&f)[32]) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) v = *(const float4 *)(row + 8 * t + 4 * h);
+    f[4 * t + 0] = v.x; f[4 * t + 1] = v.y; f[4 * t + 2] = v.z; f[4 * t + 3] = v.w;
+  }
+}
+
+// acc[row][col=lane] += sum_d Lds[row][d] * frag[d]   (A operand from LDS rows, B operand = lane's fragment)
+__device__ inline void mfma_lds_x_frag(const float *lds_tile, int l31, int h, const float (&frag)[32], f32x16 &acc) {
+  const float *rp = lds_tile + l31 * TS + 4 * h;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    float4 a = *(const float4 *)(rp + 8 * t);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, frag[4 * t + 0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, frag[4 * t + 1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, frag[4 * t + 2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, frag[4 * t + 3], acc, 0, 0, 0);
+  }
+}
+
+// acc[row][col=lane] += sum_d frag[d] * Lds[col][d]   (A operand = lane's fragment as a row, B from LDS rows)
+__device__ inline void mfma_frag_x_lds(const float (&frag)[32], const float *lds_tile, int l31, int h, f32x16 &acc) {
+  const float *rp = lds_tile + l31 * TS + 4 * h;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    float4 b = *(const float4 *)(rp + 8 * t);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(frag[4 * t + 0], b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(frag[4 * t + 1], b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(frag[4 * t + 2], b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(frag[4 * t + 3], b.w, acc, 0, 0, 0);
+  }
+}
+
+// out[r][col=lane] += sum over the 32 rows j of X of  Lds[j][r_off + r] * X[j][col]
+// (X = an accumulator tile used as the B operand; A operand = column slice of an LDS tile)
+__device__ inline void mfma_ldsT_x_acc(const float *lds_tile, int col_off, int l31, int h, const f32x16 &x, f32x16 &out) {
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    float a = lds_tile[acc_row(g, h) * TS + col_off + l31];
+    out = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x[g], out, 0, 0, 0);
+  }
+}
+
+// Stage a 32-row x 64-float tile (rows t0.. of tensor `which`) into LDS with stride TS; rows >= T are zero.
+__device__ inline void tile_prefetch(const float *qkv, int b, int hd, int which, int t0, int T, int nh, int tid, float4 (&r)[2]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    int e = q * 256 + tid;
+    int row = e >> 4, c4 = (e & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t0 + row < T) v = *(const float4 *)(qkv_row(qkv, b, t0 + row, which, hd, T, nh) + c4);
+    r[q] = v;
+  }
+}
+__device__ inline void tile_store(float *lds_tile, int tid, const float4 (&r)[2]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    int e = q * 256 + tid;
+    int row = e >> 4, c4 = (e & 15) * 4;
+    *(float4 *)&lds_tile[row * TS + c4] = r[q];
+  }
+}
+// Same for a (b, t, nh*64) tensor (out / grad_out): head slice of 64 floats per token.
+__device__ inline void tile_prefetch_o(const float *o, int b, int hd, int t0, int T, int nh, int tid, float4 (&r)[2]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    int e = q * 256 + tid;
+    int row = e >> 4, c4 = (e & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t0 + row < T) v = *(const float4 *)(o + (((int64_t)b * T + t0 + row) * nh + hd) * HD + c4);
+    r[q] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// forward: block = (128 queries, head, batch); wave = 32 queries; loop over 32-key tiles
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float *__restrict__ qkv, int T, int nh, float scale, float *__restrict__ out,
+                                                       float *__restrict__ lse) {
+  __shared__ __attribute__((aligned(16))) float Ks[32 * TS];
+  __shared__ __attribute__((aligned(16))) float Vs[32 * TS];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int hd = blockIdx.y, b = blockIdx.z;
+  const int q = blockIdx.x * 128 + wave * 32 + l31;   // this lane's query (the accumulator column)
+  const bool qv = q < T;
+  const float sl2 = scale * LOG2E;
+
+  float qf[32];
+  load_frag(qkv_row(qkv, b, qv ? q : 0, 0, hd, T, nh), h, qv, qf);
+
+  f32x16 o0, o1;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) o0[g] = o1[g] = 0.f;
+  float m = -INFINITY, l = 0.f;
+
+  const int ntiles = (T + 31) / 32;
+  float4 rk[2], rv[2];
+  tile_prefetch(qkv, b, hd, 1, 0, T, nh, tid, rk);
+  tile_prefetch(qkv, b, hd, 2, 0, T, nh, tid, rv);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    tile_store(Ks, tid, rk);
+    tile_store(Vs, tid, rv);
+    __syncthreads();
+    if (kt + 1 < ntiles) {
+      tile_prefetch(qkv, b, hd, 1, (kt + 1) * 32, T, nh, tid, rk);
+      tile_prefetch(qkv, b, hd, 2, (kt + 1) * 32, T, nh, tid, rv);
+    }
+    // S^T[key][q]: rows = keys of this tile, column = this lane's query
+    f32x16 st;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) st[g] = 0.f;
+    mfma_lds_x_frag(Ks, l31, h, qf, st);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      float s = st[g] * sl2;
+      if (kt * 32 + acc_row(g, h) >= T) s = -INFINITY;
+      st[g] = s;
+      mx = fmaxf(mx, s);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));     // the other 16 keys of the tile live in the partner half
+    const float m_new = fmaxf(m, mx);
+    const float alpha = exp2f(m - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      float p = exp2f(st[g] - m_new);
+      st[g] = p;
+      rs += p;
+    }
+    rs += __shfl_xor(rs, 32, 64);
+    l = l * alpha + rs;
+    m = m_new;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      o0[g] *= alpha;
+      o1[g] *= alpha;
+    }
+    // O^T[dv][q] += sum_key V[key][dv] * P^T[key][q]
+    mfma_ldsT_x_acc(Vs, 0, l31, h, st, o0);
+    mfma_ldsT_x_acc(Vs, 32, l31, h, st, o1);
+    __syncthreads();
+  }
+  if (qv) {
+    const float inv = 1.f / l;
+    float *op = out + (((int64_t)b * T + q) * nh + hd) * HD;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      int r = acc_row(4 * g4, h);
+      *(float4 *)(op + r) = make_float4(o0[4 * g4] * inv, o0[4 * g4 + 1] * inv, o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv);
+      *(float4 *)(op + 32 + r) = make_float4(o1[4 * g4] * inv, o1[4 * g4 + 1] * inv, o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv);
+    }
+    if (h == 0) lse[((int64_t)b * nh + hd) * T + q] = (m + log2f(l)) * LN2;   // ln sum_k exp(scale * s)
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// backward helpers
+// ---------------------------------------------------------------------------------------
+// delta[b,h,t] = sum_dv dO[b,t,h,dv] * O[b,t,h,dv]
+__global__ void attn_delta_kernel(const float *__restrict__ o, const float *__restrict__ go, int64_t rows, int T, int nh, float *__restrict__ delta) {
+  // one 16-lane group per (b, t, h) row of 64 floats
+  const int64_t gid = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
+  const int sub = threadIdx.x & 15;
+  if (gid >= rows) return;
+  float4 a = *(const float4 *)(o + gid * HD + sub * 4);
+  float4 g = *(const float4 *)(go + gid * HD + sub * 4);
+  float s = a.x * g.x + a.y * g.y + a.z * g.z + a.w * g.w;
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+  if (sub == 0) {
+    int64_t bt = gid / nh;
+    int hd = (int)(gid - bt * nh);
+    int64_t bb = bt / T;
+    int t = (int)(bt - bb * T);
+    delta[(bb * nh + hd) * T + t] = s;
+  }
+}
+
+// dK, dV: block = (128 keys, head, batch); wave = 32 keys; loop over 32-query tiles
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float *__restrict__ qkv, const float *__restrict__ go,
+                                                          const float *__restrict__ lse, const float *__restrict__ delta, int T, int nh,
+                                                          float scale, float *__restrict__ gqkv) {
+  __shared__ __attribute__((aligned(16))) float Qs[32 * TS];
+  __shared__ __attribute__((aligned(16))) float Gs[32 * TS];
+  __shared__ float s_lse[32], s_delta[32];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int hd = blockIdx.y, b = blockIdx.z;
+  const int key = blockIdx.x * 128 + wave * 32 + l31;   // accumulator column = this lane's key
+  const bool kv = key < T;
+  const float sl2 = scale * LOG2E;
+
+  float kf[32], vf[32];
+  load_frag(qkv_row(qkv, b, kv ? key : 0, 1, hd, T, nh), h, kv, kf);
+  load_frag(qkv_row(qkv, b, kv ? key : 0, 2, hd, T, nh), h, kv, vf);
+
+  f32x16 dv0, dv1, dk0, dk1;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) dv0[g] = dv1[g] = dk0[g] = dk1[g] = 0.f;
+
+  const int ntiles = (T + 31) / 32;
+  float4 rq[2], rg[2];
+  tile_prefetch(qkv, b, hd, 0, 0, T, nh, tid, rq);
+  tile_prefetch_o(go, b, hd, 0, T, nh, tid, rg);
+  for (int qt = 0; qt < ntiles; ++qt) {
+    tile_store(Qs, tid, rq);
+    tile_store(Gs, tid, rg);
+    if (tid < 32) {
+      int t = qt * 32 + tid;
+      s_lse[tid] = t < T ? lse[((int64_t)b * nh + hd) * T + t] * LOG2E : 0.f;
+      s_delta[tid] = t < T ? delta[((int64_t)b * nh + hd) * T + t] : 0.f;
+    }
+    __syncthreads();
+    if (qt + 1 < ntiles) {
+      tile_prefetch(qkv, b, hd, 0, (qt + 1) * 32, T, nh, tid, rq);
+      tile_prefetch_o(go, b, hd, (qt + 1) * 32, T, nh, tid, rg);
+    }
+    // S[q][key] and dP[q][key]: rows = queries of the tile, column = this lane's key
+    f32x16 s, dp;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s[g] = dp[g] = 0.f;
+    mfma_lds_x_frag(Qs, l31, h, kf, s);
+    mfma_lds_x_frag(Gs, l31, h, vf, dp);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      int r = acc_row(g, h);
+      bool ok = kv && (qt * 32 + r < T);
+      float p = ok ? exp2f(s[g] * sl2 - s_lse[r]) : 0.f;
+      s[g] = p;                                       // P
+      dp[g] = p * (dp[g] - s_delta[r]) * scale;        // dS
+    }
+    // dV^T[dv][key] += sum_q dO[q][dv] P[q][key];  dK^T[d][key] += sum_q Q[q][d] dS[q][key]
+    mfma_ldsT_x_acc(Gs, 0, l31, h, s, dv0);
+    mfma_ldsT_x_acc(Gs, 32, l31, h, s, dv1);
+    mfma_ldsT_x_acc(Qs, 0, l31, h, dp, dk0);
+    mfma_ldsT_x_acc(Qs, 32, l31, h, dp, dk1);
+    __syncthreads();
+  }
+  if (kv) {
+    float *kp = gqkv + ((((int64_t)b * T + key) * 3 + 1) * nh + hd) * HD;
+    float *vp = gqkv + ((((int64_t)b * T + key) * 3 + 2) * nh + hd) * HD;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      int r = acc_row(4 * g4, h);
+      *(float4 *)(kp + r) = make_float4(dk0[4 * g4], dk0[4 * g4 + 1], dk0[4 * g4 + 2], dk0[4 * g4 + 3]);
+      *(float4 *)(kp + 32 + r) = make_float4(dk1[4 * g4], dk1[4 * g4 + 1], dk1[4 * g4 + 2], dk1[4 * g4 + 3]);
+      *(float4 *)(vp + r) = make_float4(dv0[4 * g4], dv0[4 * g4 + 1], dv0[4 * g4 + 2], dv0[4 * g4 + 3]);
+      *(float4 *)(vp + 32 + r) = make_float4(dv1[4 * g4], dv1[4 * g4 + 1], dv1[4 * g4 + 2], dv1[4 * g4 + 3]);
+    }
+  }
+}
+
+// dQ: block = (128 queries, head, batch); wave = 32 queries; loop over 32-key tiles
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float *__restrict__ qkv, const float *__restrict__ go,
+                                                         const float *__restrict__ lse, const float *__restrict__ delta, int T, int nh,
+                                                         float scale, float *__restrict__ gqkv) {
+  __shared__ __attribute__((aligned(16))) float Ks[32 * TS];
+  __shared__ __attribute__((aligned(16))) float Vs[32 * TS];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int hd = blockIdx.y, b = blockIdx.z;
+  const int q = blockIdx.x * 128 + wave * 32 + l31;
+  const bool qv = q < T;
+  const float sl2 = scale * LOG2E;
+
+  float qf[32], gf[32];
+  load_frag(qkv_row(qkv, b, qv ? q : 0, 0, hd, T, nh), h, qv, qf);
+  load_frag(go + (((int64_t)b * T + (qv ? q : 0)) * nh + hd) * HD, h, qv, gf);
+  const float my_lse = qv ? lse[((int64_t)b * nh + hd) * T + q] * LOG2E : 0.f;
+  const float my_delta = qv ? delta[((int64_t)b * nh + hd) * T + q] : 0.f;
+
+  f32x16 dq0, dq1;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) dq0[g] = dq1[g] = 0.f;
+
+  const int ntiles = (T + 31) / 32;
+  float4 rk[2], rv[2];
+  tile_prefetch(qkv, b, hd, 1, 0, T, nh, tid, rk);
+  tile_prefetch(qkv, b, hd, 2, 0, T, nh, tid, rv);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    tile_store(Ks, tid, rk);
+    tile_store(Vs, tid, rv);
+    __syncthreads();
+    if (kt + 1 < ntiles) {
+      tile_prefetch(qkv, b, hd, 1, (kt + 1) * 32, T, nh, tid, rk);
+      tile_prefetch(qkv, b, hd, 2, (kt + 1) * 32, T, nh, tid, rv);
+    }
+    // S^T[key][q], dP^T[key][q]
+    f32x16 st, dpt;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) st[g] = dpt[g] = 0.f;
+    mfma_lds_x_frag(Ks, l31, h, qf, st);
+    mfma_lds_x_frag(Vs, l31, h, gf, dpt);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      bool ok = qv && (kt * 32 + acc_row(g, h) < T);
+      float p = ok ? exp2f(st[g] * sl2 - my_lse) : 0.f;
+      dpt[g] = p * (dpt[g] - my_delta) * scale;   // dS^T
+    }
+    // dQ^T[d][q] += sum_key K[key][d] dS^T[key][q]
+    mfma_ldsT_x_acc(Ks, 0, l31, h, dpt, dq0);
+    mfma_ldsT_x_acc(Ks, 32, l31, h, dpt, dq1);
+    __syncthreads();
+  }
+  if (qv) {
+    float *qp = gqkv + ((((int64_t)b * T + q) * 3 + 0) * nh + hd) * HD;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      int r = acc_row(4 * g4, h);
+      *(float4 *)(qp + r) = make_float4(dq0[4 * g4], dq0[4 * g4 + 1], dq0[4 * g4 + 2], dq0[4 * g4 + 3]);
+      *(float4 *)(qp + 32 + r) = make_float4(dq1[4 * g4], dq1[4 * g4 + 1], dq1[4 * g4 + 2], dq1[4 * g4 + 3]);
+    }
+  }
+}
+
+static int attn_check(const char *who, int b, int t, int h, int d) {
+  FTX_REQUIRE(b >= 1 && t >= 1 && h >= 1, "%s: bad size", who);
+  FTX_REQUIRE(d == HD, "%s: head dim must be 64 (got %d)", who, d);
+  FTX_REQUIRE(b <= 65535 && h <= 65535, "%s: batch / heads exceed the grid limits", who);
+  return FTX_OK;
+}
+
+extern "C" int ftx_attn_fwd(const float *qkv, int32_t b, int32_t t, int32_t h, int32_t d, float scale, float *out, float *lse, void *stream) {
+  int rc = attn_check("ftx_attn_fwd", b, t, h, d);
+  if (rc != FTX_OK) return rc;
+  FTX_REQUIRE(qkv && out && lse, "ftx_attn_fwd: null pointer");
+  dim3 grid((unsigned)ceil_div(t, 128), (unsigned)h, (unsigned)b);
+  attn_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(qkv, t, h, scale, out, lse);
+  return check_launch("ftx_attn_fwd");
+}
+
+extern "C" size_t ftx_attn_bwd_workspace_bytes(int32_t b, int32_t t, int32_t h) {
+  if (b <= 0 || t <= 0 || h <= 0) return 256;
+  return sizeof(float) * (size_t)b * t * h + 256;
+}
+
+extern "C" int ftx_attn_bwd(const float *qkv, const float *out, const float *grad_out, const float *lse, int32_t b, int32_t t, int32_t h,
+                            int32_t d, float scale, float *grad_qkv, void *workspace, size_t workspace_bytes, void *stream) {
+  int rc = attn_check("ftx_attn_bwd", b, t, h, d);
+  if (rc != FTX_OK) return rc;
+  FTX_REQUIRE(qkv && out && grad_out && lse && grad_qkv && workspace, "ftx_attn_bwd: null pointer");
+  if (workspace_bytes < ftx_attn_bwd_workspace_bytes(b, t, h)) {
+    set_error("ftx_attn_bwd: workspace %zu < required %zu", workspace_bytes, ftx_attn_bwd_workspace_bytes(b, t, h));
+    return FTX_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float *delta = (float *)workspace;
+  const int64_t rows = (int64_t)b * t * h;
+  attn_delta_kernel<<<(unsigned)ceil_div(rows * 16, 256), 256, 0, st>>>(out, grad_out, rows, t, h, delta);
+  dim3 grid((unsigned)ceil_div(t, 128), (unsigned)h, (unsigned)b);
+  attn_bwd_kv_kernel<<<grid, 256, 0, st>>>(qkv, grad_out, lse, delta, t, h, scale, grad_qkv);
+  attn_bwd_q_kernel<<<grid, 256, 0, st>>>(qkv, grad_out, lse, delta, t, h, scale, grad_qkv);
+  return check_launch("ftx_attn_bwd");
+}

@@ -563,3 +563,37 @@ class _ResampleNearest(torch.autograd.Function):
 def resample_nearest(x, size):
     """nn.Upsample(size) (nearest) on NCHW."""
     return _ResampleNearest.apply(x, size[0], size[1])
+
+
+# ---------------------------------------------------------------- ViT self-attention
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, scale):
+        L = _lib.load()
+        qkv = req(qkv.contiguous(), F32, "attention qkv", 5)
+        b, t, three, h, d = qkv.shape
+        if three != 3 or d != 64:
+            raise ValueError(f"attention: qkv must be (B, T, 3, heads, 64), got {tuple(qkv.shape)}")
+        out = _empty((b, t, h * d), F32, qkv)
+        lse = _empty((b, h, t), F32, qkv)
+        check(L.ftx_attn_fwd(ptr(qkv), b, t, h, d, float(scale), ptr(out), ptr(lse), stream()), "ftx_attn_fwd")
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.scale = float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        L = _lib.load()
+        qkv, out, lse = ctx.saved_tensors
+        b, t, _, h, d = qkv.shape
+        go = req(go.contiguous(), F32, "attention grad", 3)
+        gqkv = torch.empty_like(qkv)
+        ws_bytes = int(L.ftx_attn_bwd_workspace_bytes(b, t, h))
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=qkv.device)
+        check(L.ftx_attn_bwd(ptr(qkv), ptr(out), ptr(go), ptr(lse), b, t, h, d, ctx.scale, ptr(gqkv), ptr(ws), ws_bytes, stream()), "ftx_attn_bwd")
+        return gqkv, None
+
+
+def attention(qkv, scale):
+    """softmax(Q K^T * scale) V for qkv (B, T, 3, heads, 64) -> (B, T, heads*64)."""
+    return _Attention.apply(qkv, scale)

@@ -106,7 +106,7 @@ class Net2DBillinear(nn.Module):
             ckpt = torch.load(kw["IMAGE_PRETRAINED_PATH"], map_location="cpu", weights_only=True)["state_dict"]
             new_state_dict = OrderedDict((k.replace("backbone.", ""), v) for k, v in ckpt.items() if "backbone" in k)
             self.backbone.load_state_dict(new_state_dict)
-        self.backbone.set_attention_impl(kw.get("attn_impl", "torch"))
+        self.backbone.set_attention_impl(kw.get("attn_impl", "ftx"))
         # Parameters that can never receive a gradient (the reference needs
         # find_unused_parameters=True for them, TorchpackInterface.py:81): the final `norm`
         # (forward_blocks never applies it) and blocks past the last tap.  Their .grad stays None

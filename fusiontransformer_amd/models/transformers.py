@@ -43,7 +43,7 @@ class Attention(nn.Module):
         self.attn_drop = nn.Dropout(attn_drop)
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
-        self.attn_impl = "torch"
+        self.attn_impl = "ftx"
 
     def forward(self, x):
         B, N, C = x.shape

@@ -165,6 +165,16 @@ int ftx_bn_eval_fwd(const float *x, const float *residual, const float *gamma, c
  * grad_x (n,c), grad_residual (n,c, may be NULL), grad_gamma (c), grad_beta (c). */
 int ftx_bn_train_bwd(const float *grad_y, const float *x, const float *y, const float *gamma, const float *save_mean, const float *save_invstd, int64_t n, int32_t c, int32_t relu, float *grad_x, float *grad_residual, float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- ViT self-attention (timm Attention.forward): models/transformers.py:36-37 ----
+ * Fused softmax(Q K^T * scale) V on exact-fp32 MFMA; the (t, t) score matrix is never stored. */
+
+/* qkv (b, t, 3, h, d) float32 exactly as the fused qkv Linear produces it; out (b, t, h*d);
+ * lse (b, h, t) float32 = ln sum_k exp(scale * q.k), saved for the backward.  d must be 64. */
+int ftx_attn_fwd(const float *qkv, int32_t b, int32_t t, int32_t h, int32_t d, float scale, float *out, float *lse, void *stream);
+/* grad_qkv (b, t, 3, h, d) fully written.  workspace: ftx_attn_bwd_workspace_bytes(b, t, h). */
+size_t ftx_attn_bwd_workspace_bytes(int32_t b, int32_t t, int32_t h);
+int ftx_attn_bwd(const float *qkv, const float *out, const float *grad_out, const float *lse, int32_t b, int32_t t, int32_t h, int32_t d, float scale, float *grad_qkv, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -301,6 +301,41 @@ def test_lift_gather_and_resample_match_golden_rule(env):
     np.testing.assert_allclose(ig.grad.cpu().numpy(), it.grad.numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("B,T,H", [(2, 578, 12), (1, 33, 2), (1, 128, 1), (3, 257, 4)])
+def test_attention_matches_timm_formula(env, B, T, H):
+    """fused attention vs the three explicit ops of timm's Attention.forward (fp64 reference)."""
+    spf, O = env
+    rng = np.random.default_rng(10)
+    qkv = rng.standard_normal((B, T, 3, H, 64)).astype(np.float32)
+    go = rng.standard_normal((B, T, H * 64)).astype(np.float32)
+    scale = 64 ** -0.5
+    r = torch.from_numpy(qkv).double().requires_grad_(True)
+    q, k, v = r.permute(2, 0, 3, 1, 4)
+    attn = ((q @ k.transpose(-2, -1)) * scale).softmax(dim=-1)
+    ref = (attn @ v).transpose(1, 2).reshape(B, T, H * 64)
+    ref.backward(torch.from_numpy(go).double())
+    x = dev(qkv).requires_grad_(True)
+    out = spf.attention(x, scale)
+    out.backward(dev(go))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), r.grad.numpy(), rtol=1e-3, atol=2e-5)
+
+
+def test_attention_large_logits_are_stable(env):
+    spf, O = env
+    rng = np.random.default_rng(11)
+    qkv = rng.standard_normal((1, 100, 3, 2, 64)).astype(np.float32)
+    qkv[:, :, :2] *= 30.0   # scores ~ +-7000: online softmax must not overflow
+    x = dev(qkv).requires_grad_(True)
+    out = spf.attention(x, 0.125)
+    out.sum().backward()
+    assert torch.isfinite(out).all() and torch.isfinite(x.grad).all()
+    r = torch.from_numpy(qkv).double()
+    q, k, v = r.permute(2, 0, 3, 1, 4)
+    ref = (((q @ k.transpose(-2, -1)) * 0.125).softmax(-1) @ v).transpose(1, 2).reshape(1, 100, 128)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.numpy(), rtol=1e-3, atol=1e-4)
+
+
 def test_bad_arguments_fail_loudly(env):
     spf, O = env
     with pytest.raises(ValueError):
