@@ -2,7 +2,11 @@
 // nearest-upsample + per-point lift gather, and the NCHW nearest resample.
 // HBM-bound row gathers/scatters: one thread moves 16 bytes of one row, lanes of a
 // wave cover consecutive 16-byte pieces of the same row (coalesced 128..1024 B).
+#include <cstring>
+#include <cstdlib>
 #include "ftx_common.h"
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 using namespace ftx;
 
@@ -140,6 +144,152 @@ extern "C" int ftx_devoxelize_bwd(const float *grad_out, const int32_t *idx, con
   if (n == 0) return FTX_OK;
   devoxelize_bwd_kernel<<<grid_for(n * (c / 4), 256), 256, 0, st>>>(grad_out, idx, weights, n, c, m, grad_feats);
   return check_launch("ftx_devoxelize_bwd");
+}
+
+// ---------------------------------------------------------------- sorted segments (no float atomics)
+// The scatter sides of voxelize (forward) and devoxelize (backward) as gather-reduces: entries
+// are sorted by destination row once per (batch, stride); each destination then sums its own
+// entries in ascending entry order -> plain loads/stores at stream rate instead of the ~1.3 TB/s
+// float-atomic rate, and bit-reproducible.
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct SegLayout {
+  size_t off_keys_in, off_keys_out, off_vals_in, off_tmp, tmp_bytes, total;
+};
+
+static int seg_layout(int64_t n, int64_t m, SegLayout *L) {
+  size_t sort_bytes = 0, scan_bytes = 0;
+  int32_t *kp = nullptr;
+  if (rocprim::radix_sort_pairs(nullptr, sort_bytes, kp, kp, kp, kp, (size_t)n, 0u, 32u) != hipSuccess ||
+      rocprim::exclusive_scan(nullptr, scan_bytes, kp, kp, 0, (size_t)(m + 1), rocprim::plus<int32_t>()) != hipSuccess) {
+    set_error("ftx_segment_build: rocprim size query failed");
+    return FTX_ELAUNCH;
+  }
+  L->off_keys_in = 0;
+  L->off_keys_out = align256(sizeof(int32_t) * n);
+  L->off_vals_in = align256(L->off_keys_out + sizeof(int32_t) * n);
+  L->off_tmp = align256(L->off_vals_in + sizeof(int32_t) * n);
+  L->tmp_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
+  L->total = align256(L->off_tmp + L->tmp_bytes);
+  return FTX_OK;
+}
+
+extern "C" size_t ftx_segment_workspace_bytes(int64_t n, int64_t m) {
+  if (n <= 0 || m < 0) return 256;
+  SegLayout L;
+  if (seg_layout(n, m, &L) != FTX_OK) return 0;
+  return L.total;
+}
+
+__global__ void seg_prepare_kernel(const int32_t *__restrict__ keys, int64_t n, int64_t m, int32_t *__restrict__ keys_in,
+                                   int32_t *__restrict__ vals_in, int32_t *__restrict__ counts) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int32_t k = keys[i];
+    bool ok = k >= 0 && k < m;
+    keys_in[i] = ok ? k : (int32_t)m;   // invalid entries sort to the end
+    vals_in[i] = (int32_t)i;
+    if (ok) atomicAdd(&counts[k], 1);
+  }
+}
+
+extern "C" int ftx_segment_build(const int32_t *keys, int64_t n, int64_t m, int32_t *order, int32_t *seg_off, void *workspace,
+                                 size_t workspace_bytes, void *stream) {
+  FTX_REQUIRE(n >= 0 && m >= 0 && n < 0x7fffffff && m < 0x7ffffffe, "ftx_segment_build: bad size");
+  FTX_REQUIRE(seg_off, "ftx_segment_build: null seg_off");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(seg_off, 0, sizeof(int32_t) * (m + 1), st) != hipSuccess) return check_launch("ftx_segment_build memset");
+  if (n == 0) return FTX_OK;
+  FTX_REQUIRE(keys && order && workspace, "ftx_segment_build: null pointer");
+  SegLayout L;
+  int rc = seg_layout(n, m, &L);
+  if (rc != FTX_OK) return rc;
+  if (workspace_bytes < L.total) {
+    set_error("ftx_segment_build: workspace %zu < required %zu", workspace_bytes, L.total);
+    return FTX_EWORKSPACE;
+  }
+  char *ws = (char *)workspace;
+  int32_t *keys_in = (int32_t *)(ws + L.off_keys_in), *keys_out = (int32_t *)(ws + L.off_keys_out), *vals_in = (int32_t *)(ws + L.off_vals_in);
+  void *tmp = ws + L.off_tmp;
+  seg_prepare_kernel<<<grid_for(n, 256), 256, 0, st>>>(keys, n, m, keys_in, vals_in, seg_off);  // seg_off holds the counts for now
+  size_t tb = L.tmp_bytes;
+  unsigned bits = 1;
+  while ((1ll << bits) <= m) ++bits;
+  if (rocprim::radix_sort_pairs(tmp, tb, keys_in, keys_out, vals_in, order, (size_t)n, 0u, bits, st) != hipSuccess) {
+    set_error("ftx_segment_build: sort failed");
+    return FTX_ELAUNCH;
+  }
+  tb = L.tmp_bytes;
+  if (rocprim::exclusive_scan(tmp, tb, seg_off, seg_off, 0, (size_t)(m + 1), rocprim::plus<int32_t>(), st) != hipSuccess) {
+    set_error("ftx_segment_build: scan failed");
+    return FTX_ELAUNCH;
+  }
+  return check_launch("ftx_segment_build");
+}
+
+// out[v,:] = sum over the entries e of segment v of  scale(e) * src[row(e),:]
+//   voxelize fwd:    row(e) = e,      scale = 1 / (segment length)
+//   devoxelize bwd:  row(e) = e >> 3, scale = w[e]
+template <bool DEVOX>
+__global__ void segment_reduce_kernel(const float *__restrict__ src, const float *__restrict__ w, const int32_t *__restrict__ order,
+                                      const int32_t *__restrict__ seg_off, int64_t m, int c, float *__restrict__ out) {
+  const int cv = c >> 2;
+  const int64_t total = m * cv;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t v = t / cv;
+    int j = (int)(t - v * cv) * 4;
+    const int lo = seg_off[v], hi = seg_off[v + 1];
+    const float inv = DEVOX ? 1.f : (float)(hi - lo);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int e = lo;
+    for (; e + 4 <= hi; e += 4) {   // four independent row loads in flight
+      int32_t o0 = order[e], o1 = order[e + 1], o2 = order[e + 2], o3 = order[e + 3];
+      float4 f0 = *(const float4 *)&src[(int64_t)(DEVOX ? o0 >> 3 : o0) * c + j];
+      float4 f1 = *(const float4 *)&src[(int64_t)(DEVOX ? o1 >> 3 : o1) * c + j];
+      float4 f2 = *(const float4 *)&src[(int64_t)(DEVOX ? o2 >> 3 : o2) * c + j];
+      float4 f3 = *(const float4 *)&src[(int64_t)(DEVOX ? o3 >> 3 : o3) * c + j];
+      if (DEVOX) {
+        float w0 = w[o0], w1 = w[o1], w2 = w[o2], w3 = w[o3];
+        acc.x += w0 * f0.x; acc.y += w0 * f0.y; acc.z += w0 * f0.z; acc.w += w0 * f0.w;
+        acc.x += w1 * f1.x; acc.y += w1 * f1.y; acc.z += w1 * f1.z; acc.w += w1 * f1.w;
+        acc.x += w2 * f2.x; acc.y += w2 * f2.y; acc.z += w2 * f2.z; acc.w += w2 * f2.w;
+        acc.x += w3 * f3.x; acc.y += w3 * f3.y; acc.z += w3 * f3.z; acc.w += w3 * f3.w;
+      } else {
+        acc.x += f0.x / inv; acc.y += f0.y / inv; acc.z += f0.z / inv; acc.w += f0.w / inv;
+        acc.x += f1.x / inv; acc.y += f1.y / inv; acc.z += f1.z / inv; acc.w += f1.w / inv;
+        acc.x += f2.x / inv; acc.y += f2.y / inv; acc.z += f2.z / inv; acc.w += f2.w / inv;
+        acc.x += f3.x / inv; acc.y += f3.y / inv; acc.z += f3.z / inv; acc.w += f3.w / inv;
+      }
+    }
+    for (; e < hi; ++e) {
+      int32_t o = order[e];
+      float4 f = *(const float4 *)&src[(int64_t)(DEVOX ? o >> 3 : o) * c + j];
+      if (DEVOX) {
+        float wk = w[o];
+        acc.x += wk * f.x; acc.y += wk * f.y; acc.z += wk * f.z; acc.w += wk * f.w;
+      } else {
+        acc.x += f.x / inv; acc.y += f.y / inv; acc.z += f.z / inv; acc.w += f.w / inv;
+      }
+    }
+    *(float4 *)&out[v * c + j] = acc;
+  }
+}
+
+extern "C" int ftx_voxelize_fwd_sorted(const float *feats, const int32_t *order, const int32_t *seg_off, int64_t n, int32_t c, int64_t m,
+                                       float *out, void *stream) {
+  FTX_REQUIRE(n >= 0 && m >= 0 && c >= 4 && c % 4 == 0, "ftx_voxelize_fwd_sorted: bad size (c must be a multiple of 4)");
+  if (m == 0) return FTX_OK;
+  FTX_REQUIRE(seg_off && out && ((feats && order) || n == 0), "ftx_voxelize_fwd_sorted: null pointer");
+  segment_reduce_kernel<false><<<grid_for(m * (c / 4), 256), 256, 0, (hipStream_t)stream>>>(feats, nullptr, order, seg_off, m, c, out);
+  return check_launch("ftx_voxelize_fwd_sorted");
+}
+
+extern "C" int ftx_devoxelize_bwd_sorted(const float *grad_out, const float *weights, const int32_t *order, const int32_t *seg_off, int64_t n,
+                                         int32_t c, int64_t m, float *grad_feats, void *stream) {
+  FTX_REQUIRE(n >= 0 && m >= 0 && c >= 4 && c % 4 == 0, "ftx_devoxelize_bwd_sorted: bad size (c must be a multiple of 4)");
+  if (m == 0) return FTX_OK;
+  FTX_REQUIRE(seg_off && grad_feats && ((grad_out && weights && order) || n == 0), "ftx_devoxelize_bwd_sorted: null pointer");
+  segment_reduce_kernel<true><<<grid_for(m * (c / 4), 256), 256, 0, (hipStream_t)stream>>>(grad_out, weights, order, seg_off, m, c, grad_feats);
+  return check_launch("ftx_devoxelize_bwd_sorted");
 }
 
 // ---------------------------------------------------------------- lift gather

@@ -547,8 +547,10 @@ static int wgrad_slices(int64_t n_pairs, int ca, int cg, int kvol) {
   int wm, nt;
   wgrad_config(ca, cg, &wm, &nt);
   int64_t tiles = (int64_t)kvol * ceil_div(ca, 32 * wm) * ceil_div(cg, 32 * nt);
-  int64_t want = ceil_div(1536, tiles);                         // ~6 blocks per CU
-  int64_t max_slices = ceil_div(ceil_div(n_pairs, kvol), 256);  // keep >= ~256 pairs per slice
+  static const int target = getenv("FTX_WGRAD_BLOCKS") ? atoi(getenv("FTX_WGRAD_BLOCKS")) : 1536;  // ~6 blocks per CU
+  static const int min_pairs = getenv("FTX_WGRAD_MIN_PAIRS") ? atoi(getenv("FTX_WGRAD_MIN_PAIRS")) : 256;
+  int64_t want = ceil_div(target, tiles);
+  int64_t max_slices = ceil_div(ceil_div(n_pairs, kvol), min_pairs);  // keep >= ~min_pairs pairs per slice
   if (want > max_slices) want = max_slices;
   if (want < 1) want = 1;
   if (want > 64) want = 64;

@@ -182,9 +182,37 @@ def calc_ti_weights(pc: torch.Tensor, idx_query: torch.Tensor, scale: int = 1) -
 
 
 # ---------------------------------------------------------------- voxelize / devoxelize
+class Segments:
+    """Entries sorted by destination row (ftx_segment_build): `order`, `seg_off`, `m` rows."""
+    __slots__ = ("order", "seg_off", "m")
+
+    def __init__(self, keys: torch.Tensor, m: int):
+        L = _lib.load()
+        keys = req(keys.contiguous().view(-1), I32, "segment keys", 1)
+        n = keys.shape[0]
+        self.m = int(m)
+        self.order = _empty((n,), I32, keys)
+        self.seg_off = _empty((self.m + 1,), I32, keys)
+        ws_bytes = int(L.ftx_segment_workspace_bytes(n, self.m))
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=keys.device)
+        check(L.ftx_segment_build(ptr(keys), n, self.m, ptr(self.order), ptr(self.seg_off), ptr(ws), ws_bytes, stream()), "ftx_segment_build")
+
+
+def voxelize_segments(idx: torch.Tensor, m: int) -> Segments:
+    """Points sorted by their voxel: makes the scatter-mean of spvoxelize a gather-reduce."""
+    return Segments(idx, m)
+
+
+def devoxelize_segments(idx: torch.Tensor, weights: torch.Tensor, m: int) -> Segments:
+    """(point, corner) entries sorted by voxel, zero-weight corners dropped: makes the scatter-add of
+    spdevoxelize's backward a gather-reduce."""
+    keys = torch.where(weights != 0, idx, torch.full_like(idx, -1))
+    return Segments(keys, m)
+
+
 class _Voxelize(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, idx, counts):
+    def forward(ctx, feats, idx, counts, seg):
         L = _lib.load()
         feats = req(feats.contiguous(), F32, "spvoxelize feats", 2)
         req(idx, I32, "spvoxelize idx", 1)
@@ -194,7 +222,12 @@ class _Voxelize(torch.autograd.Function):
             raise ValueError("spvoxelize: idx length != rows of feats")
         m = counts.shape[0]
         out = _empty((m, c), F32, feats)
-        check(L.ftx_voxelize_fwd(ptr(feats), ptr(idx), ptr(counts), n, c, m, ptr(out), stream()), "ftx_voxelize_fwd")
+        if seg is not None and c % 4 == 0:
+            if seg.m != m or seg.order.shape[0] != n:
+                raise ValueError("spvoxelize: segments do not match idx / counts")
+            check(L.ftx_voxelize_fwd_sorted(ptr(feats), ptr(seg.order), ptr(seg.seg_off), n, c, m, ptr(out), stream()), "ftx_voxelize_fwd_sorted")
+        else:
+            check(L.ftx_voxelize_fwd(ptr(feats), ptr(idx), ptr(counts), n, c, m, ptr(out), stream()), "ftx_voxelize_fwd")
         ctx.save_for_backward(idx, counts)
         ctx.n = n
         return out
@@ -207,17 +240,18 @@ class _Voxelize(torch.autograd.Function):
         m, c = grad_out.shape
         gf = _empty((ctx.n, c), F32, grad_out)
         check(L.ftx_voxelize_bwd(ptr(grad_out), ptr(idx), ptr(counts), ctx.n, c, m, ptr(gf), stream()), "ftx_voxelize_bwd")
-        return gf, None, None
+        return gf, None, None, None
 
 
-def spvoxelize(feats, idx, counts):
-    """spf.spvoxelize (scatter-mean of point rows into voxel rows)."""
-    return _Voxelize.apply(feats, idx, counts)
+def spvoxelize(feats, idx, counts, seg=None):
+    """spf.spvoxelize (scatter-mean of point rows into voxel rows); `seg` = voxelize_segments(idx, m)
+    selects the atomic-free sorted form."""
+    return _Voxelize.apply(feats, idx, counts, seg)
 
 
 class _Devoxelize(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, idx, weights):
+    def forward(ctx, feats, idx, weights, seg):
         L = _lib.load()
         feats = req(feats.contiguous(), F32, "spdevoxelize feats", 2)
         req(idx, I32, "spdevoxelize idx", 2)
@@ -229,7 +263,7 @@ class _Devoxelize(torch.autograd.Function):
         out = _empty((n, c), F32, feats)
         check(L.ftx_devoxelize_fwd(ptr(feats), ptr(idx), ptr(weights), n, c, m, ptr(out), stream()), "ftx_devoxelize_fwd")
         ctx.save_for_backward(idx, weights)
-        ctx.m = m
+        ctx.m, ctx.seg = m, seg
         return out
 
     @staticmethod
@@ -239,13 +273,21 @@ class _Devoxelize(torch.autograd.Function):
         grad_out = req(grad_out.contiguous(), F32, "spdevoxelize grad", 2)
         n, c = grad_out.shape
         gf = _empty((ctx.m, c), F32, grad_out)
-        check(L.ftx_devoxelize_bwd(ptr(grad_out), ptr(idx), ptr(weights), n, c, ctx.m, ptr(gf), stream()), "ftx_devoxelize_bwd")
-        return gf, None, None
+        seg = ctx.seg
+        if seg is not None:
+            if seg.m != ctx.m or seg.order.shape[0] != n * 8:
+                raise ValueError("spdevoxelize: segments do not match idx")
+            check(L.ftx_devoxelize_bwd_sorted(ptr(grad_out), ptr(weights), ptr(seg.order), ptr(seg.seg_off), n, c, ctx.m, ptr(gf), stream()),
+                  "ftx_devoxelize_bwd_sorted")
+        else:
+            check(L.ftx_devoxelize_bwd(ptr(grad_out), ptr(idx), ptr(weights), n, c, ctx.m, ptr(gf), stream()), "ftx_devoxelize_bwd")
+        return gf, None, None, None
 
 
-def spdevoxelize(feats, idx, weights):
-    """spf.spdevoxelize (8-corner weighted gather of voxel rows onto points)."""
-    return _Devoxelize.apply(feats, idx, weights)
+def spdevoxelize(feats, idx, weights, seg=None):
+    """spf.spdevoxelize (8-corner weighted gather of voxel rows onto points); `seg` =
+    devoxelize_segments(idx, weights, m) makes the backward atomic-free."""
+    return _Devoxelize.apply(feats, idx, weights, seg)
 
 
 # ---------------------------------------------------------------- sparse convolution

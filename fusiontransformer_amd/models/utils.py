@@ -29,7 +29,8 @@ def initial_voxelize(z: PointTensor, init_res, after_res) -> SparseTensor:
     counts = spf.spcount(idx_query, n_vox)
     # round(mean of identical integer coordinates) == the coordinates of any member
     inserted_coords = spf.gather_coords(floored, first[:n_vox].contiguous())
-    inserted_feat = spf.spvoxelize(z.F, idx_query, counts)
+    seg = spf.voxelize_segments(idx_query, n_vox)
+    inserted_feat = spf.spvoxelize(z.F, idx_query, counts, seg)
 
     new_tensor = SparseTensor(inserted_feat, inserted_coords, 1)
     new_tensor.cm = CoordinateManager()
@@ -38,6 +39,7 @@ def initial_voxelize(z: PointTensor, init_res, after_res) -> SparseTensor:
     new_tensor.check()
     z.additional_features["idx_query"][1] = idx_query
     z.additional_features["counts"][1] = counts
+    z.additional_features.setdefault("vox_seg", {})[1] = seg
     z.C = new_float_coord
     return new_tensor
 
@@ -51,10 +53,12 @@ def point_to_voxel(x: SparseTensor, z: PointTensor) -> SparseTensor:
         counts = spf.spcount(idx_query, x.C.shape[0])
         z.additional_features["idx_query"][x.s] = idx_query
         z.additional_features["counts"][x.s] = counts
+        z.additional_features.setdefault("vox_seg", {})[x.s] = spf.voxelize_segments(idx_query, x.C.shape[0])
     else:
         idx_query = z.additional_features["idx_query"][x.s]
         counts = z.additional_features["counts"][x.s]
-    inserted_feat = spf.spvoxelize(z.F, idx_query, counts)
+    seg = z.additional_features.setdefault("vox_seg", {}).get(x.s)
+    inserted_feat = spf.spvoxelize(z.F, idx_query, counts, seg)
     return x.derive(inserted_feat)
 
 
@@ -69,7 +73,9 @@ def voxel_to_point(x: SparseTensor, z: PointTensor, nearest=False) -> PointTenso
         if nearest:
             weights[:, 1:] = 0.0
             idx_query[:, 1:] = -1
-        new_feat = spf.spdevoxelize(x.F, idx_query, weights)
+        seg = spf.devoxelize_segments(idx_query, weights, x.F.shape[0]) if x.F.requires_grad else None
+        z.additional_features.setdefault("devox_seg", {})[x.s] = seg
+        new_feat = spf.spdevoxelize(x.F, idx_query, weights, seg)
         new_tensor = PointTensor(new_feat, z.C, idx_query=z.idx_query, weights=z.weights)
         new_tensor.additional_features = z.additional_features
         new_tensor.idx_query[x.s] = idx_query
@@ -77,7 +83,10 @@ def voxel_to_point(x: SparseTensor, z: PointTensor, nearest=False) -> PointTenso
         z.idx_query[x.s] = idx_query
         z.weights[x.s] = weights
     else:
-        new_feat = spf.spdevoxelize(x.F, z.idx_query.get(x.s), z.weights.get(x.s))
+        segs = z.additional_features.setdefault("devox_seg", {})
+        if segs.get(x.s) is None and x.F.requires_grad:
+            segs[x.s] = spf.devoxelize_segments(z.idx_query.get(x.s), z.weights.get(x.s), x.F.shape[0])
+        new_feat = spf.spdevoxelize(x.F, z.idx_query.get(x.s), z.weights.get(x.s), segs.get(x.s))
         new_tensor = PointTensor(new_feat, z.C, idx_query=z.idx_query, weights=z.weights)
         new_tensor.additional_features = z.additional_features
     return new_tensor

@@ -108,6 +108,19 @@ int ftx_devoxelize_fwd(const float *feats, const int32_t *idx, const float *weig
 /* bwd: grad_feats (m,c) zeroed here; grad_feats[idx[i,k]] += w[i,k] * grad_out[i]. */
 int ftx_devoxelize_bwd(const float *grad_out, const int32_t *idx, const float *weights, int64_t n, int32_t c, int64_t m, float *grad_feats, void *stream);
 
+/* Sorted-segment forms of the two scatter sides (no float atomics, bit-reproducible).
+ * ftx_segment_build: keys (n) int32 = destination row of each entry (<0 or >=m: dropped);
+ *   order (n) int32 receives the entry ids sorted by destination (ties in ascending entry id),
+ *   seg_off (m+1) int32 the first position of every destination's run.
+ * voxelize:   keys = idx (point -> voxel), entries = points.
+ * devoxelize: keys = idx (n,8) flattened with zero-weight corners set to -1, entries = (point, corner). */
+size_t ftx_segment_workspace_bytes(int64_t n, int64_t m);
+int ftx_segment_build(const int32_t *keys, int64_t n, int64_t m, int32_t *order, int32_t *seg_off, void *workspace, size_t workspace_bytes, void *stream);
+/* out[v] = mean of feats[p] over the points p of voxel v (0 for empty voxels); out (m,c) fully written. */
+int ftx_voxelize_fwd_sorted(const float *feats, const int32_t *order, const int32_t *seg_off, int64_t n, int32_t c, int64_t m, float *out, void *stream);
+/* grad_feats[v] = sum over entries e=(p,k) of voxel v of weights[e] * grad_out[p]; weights (n,8) flattened, n = points. */
+int ftx_devoxelize_bwd_sorted(const float *grad_out, const float *weights, const int32_t *order, const int32_t *seg_off, int64_t n, int32_t c, int64_t m, float *grad_feats, void *stream);
+
 /* ---- 2D -> 3D lift ------------------------------------------------------- */
 
 /* Fused `nn.Upsample((H,W))` (nearest) + per-point gather of

@@ -121,6 +121,13 @@ def test_voxelize_devoxelize_fwd_bwd(env, c):
     yo = O.spvoxelize(xo, idx, counts)
     yg = spf.spvoxelize(xg, dev(idx), dev(counts))
     np.testing.assert_allclose(yg.detach().cpu().numpy(), yo.detach().numpy(), rtol=1e-5, atol=1e-5)
+    # sorted-segment form (no atomics): same result, bit-identical from run to run
+    seg = spf.voxelize_segments(dev(idx), m)
+    ys = [spf.spvoxelize(dev(x), dev(idx), dev(counts), seg) for _ in range(2)]
+    np.testing.assert_allclose(ys[0].cpu().numpy(), yo.detach().numpy(), rtol=1e-5, atol=1e-5)
+    assert torch.equal(ys[0], ys[1])
+    so = seg.seg_off.cpu().numpy()
+    assert np.array_equal(np.diff(so), counts) and np.array_equal(np.sort(seg.order.cpu().numpy()[:so[-1]]), np.nonzero(idx >= 0)[0])
     go = rng.standard_normal(yo.shape).astype(np.float32)
     yo.backward(torch.from_numpy(go)); yg.backward(dev(go))
     np.testing.assert_allclose(xg.grad.cpu().numpy(), xo.grad.numpy(), rtol=1e-6, atol=1e-6)
@@ -137,6 +144,14 @@ def test_voxelize_devoxelize_fwd_bwd(env, c):
     g2 = rng.standard_normal(po.shape).astype(np.float32)
     po.backward(torch.from_numpy(g2)); pg.backward(dev(g2))
     np.testing.assert_allclose(fg.grad.cpu().numpy(), fo.grad.numpy(), rtol=1e-4, atol=1e-4)
+    dseg = spf.devoxelize_segments(dev(idx8), dev(w8), m)
+    grads = []
+    for _ in range(2):
+        f2 = dev(f).requires_grad_(True)
+        spf.spdevoxelize(f2, dev(idx8), dev(w8), dseg).backward(dev(g2))
+        grads.append(f2.grad)
+    np.testing.assert_allclose(grads[0].cpu().numpy(), fo.grad.numpy(), rtol=1e-4, atol=1e-4)
+    assert torch.equal(grads[0], grads[1])
 
 
 @pytest.mark.parametrize("ca,co,ks,cur,s", [(4, 32, 3, 1, 1), (32, 32, 3, 1, 1), (32, 64, 3, 2, 1), (64, 64, 2, 1, 2),

@@ -1,0 +1,49 @@
+"""Per-layer micro-benchmark of the sparse-conv kernels on the bench workload's real kernel maps.
+usage (GPU box): python tools/bench_spconv.py [--batch 4]"""
+import argparse, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fusiontransformer_amd import functional as spf
+from fusiontransformer_amd.data.synth import make_batch
+from fusiontransformer_amd.models.utils import initial_voxelize
+from fusiontransformer_amd.sparse import PointTensor
+
+ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=4); ap.add_argument("--iters", type=int, default=20)
+args = ap.parse_args()
+b = make_batch(list(range(args.batch)))
+z = PointTensor(torch.from_numpy(b["feats"]).cuda(), torch.from_numpy(b["coords"]).float().cuda())
+x0 = initial_voxelize(z, 1, 1)
+cm = x0.cm
+layers = []  # (name, ks, cur_stride, stride, ca, co)
+for lvl, (s, chans) in enumerate([(1, [(32, 32), (128, 96), (96, 96)]), (2, [(32, 32), (128, 96), (96, 96)]), (4, [(32, 64), (64, 64), (192, 128), (128, 128)]),
+                                   (8, [(64, 128), (128, 128), (384, 256), (256, 256)]), (16, [(128, 256), (256, 256)])]):
+    if s > 1:
+        cm.kernel_map(2, s // 2, 2)
+    for ca, co in chans:
+        layers.append(("k3 s%d %d->%d" % (s, ca, co), 3, s, 1, ca, co))
+for s, c in [(1, 32), (2, 32), (4, 64), (8, 128)]:
+    layers.append(("k2 down s%d %d->%d" % (s, c, c), 2, s, 2, c, c))
+
+def timeit(fn):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / args.iters * 1e3
+
+print("%-24s %9s %9s | %8s %8s %8s | %7s %7s" % ("layer", "rows", "pairs", "gemm us", "reduce", "wgrad", "gemmTF", "wgradTF"))
+tot = [0, 0, 0]
+for name, ks, cur, st, ca, co in layers:
+    km = cm.kernel_map(ks, cur, st)
+    A = torch.randn(km.n_in, ca, device="cuda"); W = torch.randn(ks ** 3, ca, co, device="cuda") * 0.05
+    G = torch.randn(km.n_out, co, device="cuda")
+    L = spf._lib.load()
+    tmp = torch.empty(km.n_pairs, co, device="cuda"); out = torch.empty(km.n_out, co, device="cuda")
+    t_g = timeit(lambda: L.ftx_spconv_pairs_gemm(A.data_ptr(), km.n_in, km.pair_in.data_ptr(), W.data_ptr(), 0, km.koff.data_ptr(), km.n_pairs, ca, co, ks ** 3, tmp.data_ptr(), spf.stream()))
+    t_r = timeit(lambda: L.ftx_spconv_reduce(tmp.data_ptr(), km.pos.data_ptr(), km.n_out, co, ks ** 3, out.data_ptr(), spf.stream()))
+    t_w = timeit(lambda: spf._spconv_wgrad(A, km.pair_in, G, km.pair_out, km.koff, km.n_pairs))
+    fl = 2.0 * km.n_pairs * ca * co
+    print("%-24s %9d %9d | %8.1f %8.1f %8.1f | %7.1f %7.1f" % (name, km.n_out, km.n_pairs, t_g, t_r, t_w, fl / t_g / 1e6, fl / t_w / 1e6))
+    tot[0] += t_g; tot[1] += t_r; tot[2] += t_w
+print("sum: gemm %.0f us  reduce %.0f us  wgrad %.0f us" % tuple(tot))
