@@ -48,6 +48,9 @@ SIGNATURES = {
     "ftx_lift_gather_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ftx_resample_nearest_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ftx_resample_nearest_bwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "ftx_sample_down_workspace_bytes": (_sz, []),
+    "ftx_sample_down_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "ftx_sample_down_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ftx_spconv_pairs_gemm": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "ftx_rows_gemm": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "ftx_spconv_reduce": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),

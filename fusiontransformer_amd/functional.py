@@ -639,3 +639,47 @@ class _Attention(torch.autograd.Function):
 def attention(qkv, scale):
     """softmax(Q K^T * scale) V for qkv (B, T, 3, heads, 64) -> (B, T, heads*64)."""
     return _Attention.apply(qkv, scale)
+
+
+# ---------------------------------------------------------------- fused sample_down
+class _SampleDown(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, conv_w, conv_b, gamma, beta, running_mean, running_var, momentum, eps, training, oh, ow):
+        L = _lib.load()
+        img = req(img.contiguous(), F32, "sample_down img", 4)
+        b, c, h, w = img.shape
+        if c != 3 or conv_w.numel() != 9:
+            raise ValueError("sample_down: the fused kernel is the 3 -> 3 channel BilinearModule of the reference")
+        conv_w = req(conv_w.contiguous().view(3, 3), F32, "sample_down conv weight", 2)
+        out = _empty((b, 3, int(oh), int(ow)), F32, img)
+        saved = torch.empty((33,), dtype=torch.float64, device=img.device)
+        ws_bytes = int(L.ftx_sample_down_workspace_bytes())
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=img.device)
+        check(L.ftx_sample_down_fwd(ptr(img), b, h, w, int(oh), int(ow), ptr(conv_w), ptr(conv_b), ptr(gamma), ptr(beta), ptr(running_mean),
+                                    ptr(running_var), float(momentum), float(eps), int(bool(training)), ptr(out), ptr(saved), ptr(ws), ws_bytes, stream()),
+              "ftx_sample_down_fwd")
+        ctx.save_for_backward(img, conv_w, conv_b, gamma, saved)
+        ctx.training = bool(training)
+        ctx.dims = (b, h, w, int(oh), int(ow))
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        L = _lib.load()
+        if not ctx.training:
+            raise RuntimeError("sample_down: backward is implemented for training-mode statistics only")
+        img, conv_w, conv_b, gamma, saved = ctx.saved_tensors
+        b, h, w, oh, ow = ctx.dims
+        go = req(go.contiguous(), F32, "sample_down grad", 4)
+        gw = _empty((3, 3), F32, go)
+        gb, gg, gbeta = _empty((3,), F32, go), _empty((3,), F32, go), _empty((3,), F32, go)
+        ws_bytes = int(L.ftx_sample_down_workspace_bytes())
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=go.device)
+        check(L.ftx_sample_down_bwd(ptr(img), ptr(go), b, h, w, oh, ow, ptr(conv_w), ptr(conv_b), ptr(gamma), ptr(saved), ptr(gw), ptr(gb), ptr(gg),
+                                    ptr(gbeta), ptr(ws), ws_bytes, stream()), "ftx_sample_down_bwd")
+        return None, gw, gb, gg, gbeta, None, None, None, None, None, None, None
+
+
+def sample_down(img, conv_w, conv_b, gamma, beta, running_mean, running_var, momentum, eps, training, size):
+    """Conv1x1(3->3) + ReLU + BatchNorm2d + nearest pick, fused (image_models_billinear.py:8-24)."""
+    return _SampleDown.apply(img, conv_w, conv_b, gamma, beta, running_mean, running_var, momentum, eps, training, size[0], size[1])

@@ -53,8 +53,16 @@ class BilinearModule(nn.Module):
 
     def forward(self, x):
         # stem = Conv1x1 -> ReLU -> BN2d on the full-resolution map (the batch statistics need
-        # every pixel); the 1x1 conv is a channel contraction
+        # every pixel), then the nearest pick
         conv, bn = self.stem[0], self.stem[2]
+        if conv.in_channels == 3 and conv.out_channels == 3 and (bn.training or not torch.is_grad_enabled() or not conv.weight.requires_grad):
+            if bn.training and bn.track_running_stats:
+                bn.num_batches_tracked.add_(1)
+            conv_w = conv.weight.view(3, 3)
+            if x.requires_grad:
+                raise RuntimeError("sample_down: the fused kernel does not produce a gradient for the image")
+            return spf.sample_down(x, conv_w, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                   bn.training, self.size)
         w = conv.weight.view(conv.out_channels, conv.in_channels)
         x = torch.einsum("oc,bchw->bohw", w, x) + conv.bias.view(1, -1, 1, 1)
         x = F.relu(x)

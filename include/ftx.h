@@ -137,6 +137,16 @@ int ftx_lift_gather_bwd(const float *grad_out, const int64_t *img_idx, const int
 int ftx_resample_nearest_fwd(const float *in, int32_t b, int32_t c, int32_t ih, int32_t iw, int32_t oh, int32_t ow, float *out, void *stream);
 int ftx_resample_nearest_bwd(const float *grad_out, int32_t b, int32_t c, int32_t ih, int32_t iw, int32_t oh, int32_t ow, float *grad_in, void *stream);
 
+/* Fused Net2DBillinear.sample_down: Conv1x1(3->3) + ReLU + BatchNorm2d(3) on the full-resolution
+ * image + nearest pick to (oh, ow) (models/image_models_billinear.py:8-24,41,131).
+ * img (b,3,h,w); conv_w (3,3) row-major [out][in]; out (b,3,oh,ow); saved (33) float64 device scratch
+ * kept for the backward (training statistics of the full-resolution map).  training != 0: batch
+ * statistics (running_* updated when non-NULL); training == 0: running statistics.
+ * bwd (training mode) writes the four parameter gradients; the image gets none (it is an input). */
+size_t ftx_sample_down_workspace_bytes(void);
+int ftx_sample_down_fwd(const float *img, int32_t b, int32_t h, int32_t w, int32_t oh, int32_t ow, const float *conv_w, const float *conv_b, const float *gamma, const float *beta, float *running_mean, float *running_var, float momentum, float eps, int32_t training, float *out, double *saved, void *workspace, size_t workspace_bytes, void *stream);
+int ftx_sample_down_bwd(const float *img, const float *grad_out, int32_t b, int32_t h, int32_t w, int32_t oh, int32_t ow, const float *conv_w, const float *conv_b, const float *gamma, const double *saved, float *grad_conv_w, float *grad_conv_b, float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- sparse convolution (spnn.Conv3d fwd/bwd) ----------------------------
  * Pair-list gather-GEMM + ordered reduce (exact-fp32 MFMA, no float atomics, bit-reproducible):
  *   forward       tmp = pairs_gemm(A=in,   gather=pair_in,  W, 0);  out = reduce(tmp, pos,   n_out)

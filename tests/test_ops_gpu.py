@@ -351,6 +351,33 @@ def test_attention_large_logits_are_stable(env):
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref.numpy(), rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 370, 1226), (1, 90, 160)])
+def test_fused_sample_down_matches_torch_modules(env, B, H, W):
+    """Conv1x1 -> ReLU -> BatchNorm2d(train) -> nn.Upsample((384,384)) exactly as BilinearModule composes them."""
+    spf, O = env
+    rng = np.random.default_rng(12)
+    img = rng.standard_normal((B, 3, H, W)).astype(np.float32)
+    ref = torch.nn.Sequential(torch.nn.Conv2d(3, 3, 1), torch.nn.ReLU(), torch.nn.BatchNorm2d(3), torch.nn.Upsample((384, 384))).double().train()
+    with torch.no_grad():
+        ref[2].weight.copy_(torch.tensor([1.3, 0.7, 1.1])); ref[2].bias.copy_(torch.tensor([0.1, -0.2, 0.3]))
+    yo = ref(torch.from_numpy(img).double())
+    go = rng.standard_normal(yo.shape).astype(np.float32)
+    yo.backward(torch.from_numpy(go).double())
+    cw = ref[0].weight.detach().float().view(3, 3).cuda().requires_grad_(True)
+    cb = ref[0].bias.detach().float().cuda().requires_grad_(True)
+    g = ref[2].weight.detach().float().cuda().requires_grad_(True)
+    be = ref[2].bias.detach().float().cuda().requires_grad_(True)
+    rm, rv = torch.zeros(3, device="cuda"), torch.ones(3, device="cuda")
+    yg = spf.sample_down(dev(img), cw, cb, g, be, rm, rv, 0.1, 1e-5, True, (384, 384))
+    yg.backward(dev(go))
+    np.testing.assert_allclose(yg.detach().cpu().numpy(), yo.detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rm.cpu().numpy(), ref[2].running_mean.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rv.cpu().numpy(), ref[2].running_var.numpy(), rtol=1e-5, atol=1e-6)
+    for got, want in ((cw.grad, ref[0].weight.grad.view(3, 3)), (cb.grad, ref[0].bias.grad), (g.grad, ref[2].weight.grad), (be.grad, ref[2].bias.grad)):
+        w_ = want.numpy()
+        np.testing.assert_allclose(got.cpu().numpy(), w_, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(w_).max()))
+
+
 def test_bad_arguments_fail_loudly(env):
     spf, O = env
     with pytest.raises(ValueError):
