@@ -381,8 +381,8 @@ extern "C" int ftx_spconv_reduce(const float *tmp, const int32_t *pos, int64_t n
 
 // ---------------------------------------------------------------------------------------
 // weight gradient: dW[k] = sum_{p in k} A[idx_a[p],:]^T @ G[idx_g[p],:]
-// Block (k, slice, mt, nt) reduces its slice of offset k's pairs into a 128(ca) x 128(cg) tile;
-// slices are combined by a second, ordered pass.
+// Block (tile of one offset's pairs, mt, nt) reduces its pairs into a (32 WM) x (32 NT) tile of dW[k];
+// the tiles of an offset are combined by a second, ordered pass.
 // ---------------------------------------------------------------------------------------
 constexpr int WG_BR = 32;      // pairs staged per step
 constexpr int WG_ROUND = 1024;  // pair indices kept in LDS at a time
@@ -393,7 +393,7 @@ constexpr int WG_ROUND = 1024;  // pair indices kept in LDS at a time
 template <int WM, int NT>
 __global__ __launch_bounds__(256) void pairs_wgrad_kernel(const float *__restrict__ A, int64_t rows_a, const int32_t *__restrict__ idx_a,
                                                           const float *__restrict__ G, int64_t rows_g, const int32_t *__restrict__ idx_g,
-                                                          const int32_t *__restrict__ koff, int ca, int cg, int kvol, int nslices,
+                                                          const int32_t *__restrict__ koff, int ca, int cg, int kvol, int tile_len,
                                                           float *__restrict__ part, int n_dense) {
   // idx_a == nullptr: dense mode, rows [0, n_dense) of A and G pair up one to one (kvol = 1)
   constexpr int TM = 32 * WM, TN = 32 * NT, KS = 4 / WM;
@@ -407,13 +407,39 @@ __global__ __launch_bounds__(256) void pairs_wgrad_kernel(const float *__restric
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave % WM, ks = wave / WM;
-  const int k = blockIdx.x % kvol;
-  const int slice = blockIdx.x / kvol;
+  // Tile = `tile_len` consecutive pairs of ONE offset.  Offsets differ a lot in pair count (the
+  // centre offset of a submanifold map has one pair per voxel, ~7x the others), so tiles are cut
+  // from the pair list, not per offset: a wave-level scan of koff maps block -> (offset, range).
+  __shared__ int s_tile[3];
+  if (tid < 64) {
+    const int b = blockIdx.x;
+    int c = 0;
+    if (tid < kvol) c = koff ? koff[tid + 1] - koff[tid] : n_dense;
+    int nt = (c + tile_len - 1) / tile_len;
+    int incl = nt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      int v = __shfl_up(incl, off, 64);
+      if (tid >= off) incl += v;
+    }
+    int excl = incl - nt;
+    bool mine = (tid < kvol) && b >= excl && b < incl;
+    unsigned long long msk = __ballot(mine);
+    if (mine) {
+      int t = b - excl;
+      int first = (koff ? koff[tid] : 0) + t * tile_len;
+      int left = c - t * tile_len;
+      s_tile[0] = tid;
+      s_tile[1] = first;
+      s_tile[2] = first + (left > tile_len ? tile_len : left);
+    }
+    if (msk == 0ull && tid == 0) s_tile[0] = -1;
+  }
+  __syncthreads();
+  const int k = s_tile[0];
+  if (k < 0) return;  // surplus block of the upper-bound grid
   const int m0 = blockIdx.y * TM, n0 = blockIdx.z * TN;
-  const int k_lo = koff ? koff[k] : 0, k_hi = koff ? koff[k + 1] : n_dense;
-  const int per = ((k_hi - k_lo + nslices - 1) / nslices + WG_BR - 1) / WG_BR * WG_BR;
-  const int lo = k_lo + slice * per;
-  const int hi = (lo + per < k_hi) ? lo + per : k_hi;
+  const int lo = s_tile[1], hi = s_tile[2];
 
   f32x16 acc[NT];
 #pragma unroll
@@ -421,16 +447,20 @@ __global__ __launch_bounds__(256) void pairs_wgrad_kernel(const float *__restric
 #pragma unroll
     for (int g = 0; g < 16; ++g) acc[j][g] = 0.f;
 
-  float4 ra[WM], rg[NT];
+  // Two register stages: the gathers of step s+2 are issued while step s is in the matrix cores, so
+  // a block hides its own load latency (blocks of one CU start together and stay in lockstep, so
+  // relying on the other resident blocks to cover it does not work).
+  float4 ra0[WM], rg0[NT], ra1[WM], rg1[NT];
   int rbase = lo;  // first pair of the round whose indices are in LDS
-  auto load_step = [&](int p0) {
+  int rend = lo;
+  auto load_step = [&](int p0, float4 (&ra)[WM], float4 (&rg)[NT]) {
 #pragma unroll
     for (int q = 0; q < WM; ++q) {
       int e = q * 256 + tid;
       int pr = e / (TM / 4), c4 = (e - pr * (TM / 4)) * 4;
       int p = p0 + pr;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p < hi && p - rbase < WG_ROUND && m0 + c4 < ca) {
+      if (p < rend && m0 + c4 < ca) {
         int32_t ia = s_ia[p - rbase];
         if (ia >= 0) v = *(const float4 *)&A[(int64_t)ia * ca + m0 + c4];
       }
@@ -442,16 +472,42 @@ __global__ __launch_bounds__(256) void pairs_wgrad_kernel(const float *__restric
       int pr = e / (TN / 4), c4 = (e - pr * (TN / 4)) * 4;
       int p = p0 + pr;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p < hi && p - rbase < WG_ROUND && n0 + c4 < cg) {
+      if (p < rend && n0 + c4 < cg) {
         int32_t ig = s_ig[p - rbase];
         if (ig >= 0) v = *(const float4 *)&G[(int64_t)ig * cg + n0 + c4];
       }
       rg[q] = v;
     }
   };
+  auto store_step = [&](const float4 (&ra)[WM], const float4 (&rg)[NT]) {
+#pragma unroll
+    for (int q = 0; q < WM; ++q) {
+      int e = q * 256 + tid;
+      int pr = e / (TM / 4), c4 = (e - pr * (TM / 4)) * 4;
+      *(float4 *)&As[pr * ASTR + c4] = ra[q];
+    }
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      int e = q * 256 + tid;
+      int pr = e / (TN / 4), c4 = (e - pr * (TN / 4)) * 4;
+      *(float4 *)&Gs[pr * GSTR + c4] = rg[q];
+    }
+  };
+  auto mfma_step = [&]() {
+#pragma unroll
+    for (int it = 0; it < WG_BR / 2 / KS; ++it) {
+      int kk = 2 * (it * KS + ks) + half;
+      float a = As[kk * ASTR + wm * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float b = Gs[kk * GSTR + j * 32 + l31];
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+      }
+    }
+  };
 
   for (rbase = lo; rbase < hi; rbase += WG_ROUND) {
-    const int rend = (rbase + WG_ROUND < hi) ? rbase + WG_ROUND : hi;
+    rend = (rbase + WG_ROUND < hi) ? rbase + WG_ROUND : hi;
     __syncthreads();  // previous round's gathers are done with s_ia / s_ig
     for (int t = tid; t < rend - rbase; t += 256) {
       int32_t ia = idx_a ? idx_a[rbase + t] : rbase + t, ig = idx_g ? idx_g[rbase + t] : rbase + t;
@@ -460,32 +516,19 @@ __global__ __launch_bounds__(256) void pairs_wgrad_kernel(const float *__restric
       s_ig[t] = ig;
     }
     __syncthreads();
-    load_step(rbase);
-    for (int p0 = rbase; p0 < rend; p0 += WG_BR) {
-#pragma unroll
-      for (int q = 0; q < WM; ++q) {
-        int e = q * 256 + tid;
-        int pr = e / (TM / 4), c4 = (e - pr * (TM / 4)) * 4;
-        *(float4 *)&As[pr * ASTR + c4] = ra[q];
-      }
-#pragma unroll
-      for (int q = 0; q < NT; ++q) {
-        int e = q * 256 + tid;
-        int pr = e / (TN / 4), c4 = (e - pr * (TN / 4)) * 4;
-        *(float4 *)&Gs[pr * GSTR + c4] = rg[q];
-      }
+    load_step(rbase, ra0, rg0);
+    load_step(rbase + WG_BR, ra1, rg1);
+    for (int p0 = rbase; p0 < rend; p0 += 2 * WG_BR) {
+      store_step(ra0, rg0);
       __syncthreads();
-      if (p0 + WG_BR < rend) load_step(p0 + WG_BR);
-#pragma unroll
-      for (int it = 0; it < WG_BR / 2 / KS; ++it) {
-        int kk = 2 * (it * KS + ks) + half;
-        float a = As[kk * ASTR + wm * 32 + l31];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          float b = Gs[kk * GSTR + j * 32 + l31];
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
-        }
-      }
+      load_step(p0 + 2 * WG_BR, ra0, rg0);
+      mfma_step();
+      __syncthreads();
+      if (p0 + WG_BR >= rend) break;
+      store_step(ra1, rg1);
+      __syncthreads();
+      load_step(p0 + 3 * WG_BR, ra1, rg1);
+      mfma_step();
       __syncthreads();
     }
   }
@@ -510,7 +553,7 @@ __global__ __launch_bounds__(256) void pairs_wgrad_kernel(const float *__restric
   }
 
   if (ks == 0) {
-    float *dst = part + ((int64_t)slice * kvol + k) * ca * cg;
+    float *dst = part + (int64_t)blockIdx.x * ca * cg;   // one partial per tile, tiles are numbered in offset order
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       int col = n0 + j * 32 + l31;
@@ -525,15 +568,42 @@ __global__ __launch_bounds__(256) void pairs_wgrad_kernel(const float *__restric
   }
 }
 
-__global__ void wgrad_reduce_kernel(const float *__restrict__ part, int64_t elems, int nslices, float *__restrict__ dW) {
-  for (int64_t e = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; e < elems; e += (int64_t)gridDim.x * blockDim.x * 4) {
-    float4 s = *(const float4 *)&part[e];
-    for (int c = 1; c < nslices; ++c) {
-      float4 v = *(const float4 *)&part[(int64_t)c * elems + e];
+// dW[k] = sum of the partial tiles of offset k (tiles are numbered in offset order).  Block =
+// (256/TL) float4 columns x TL tile lanes; lane l sums tiles l, l+TL, ... and the TL lane sums are
+// added in lane order through LDS: a fixed summation tree, bit-reproducible.
+template <int TL>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, const int32_t *__restrict__ koff, int kvol,
+                                                           int tile_len, int n_dense, int64_t mat, float *__restrict__ dW) {
+  constexpr int COLS = 256 / TL;
+  __shared__ float4 sh[TL][COLS];
+  const int k = blockIdx.y;
+  int first = 0, cnt = 0;
+  for (int q = 0; q <= k; ++q) {
+    int c = koff ? koff[q + 1] - koff[q] : n_dense;
+    int nt = (c + tile_len - 1) / tile_len;
+    if (q < k) first += nt; else cnt = nt;
+  }
+  const int col = threadIdx.x % COLS, tl = threadIdx.x / COLS;
+  const int64_t e = ((int64_t)blockIdx.x * COLS + col) * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e < mat) {
+    for (int t = tl; t < cnt; t += TL) {
+      float4 v = *(const float4 *)&part[(int64_t)(first + t) * mat + e];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    *(float4 *)&dW[e] = s;
   }
+  if (TL > 1) {
+    sh[tl][col] = s;
+    __syncthreads();
+    if (tl == 0) {
+#pragma unroll
+      for (int l = 1; l < TL; ++l) {
+        float4 v = sh[l][col];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    }
+  }
+  if (tl == 0 && e < mat) *(float4 *)&dW[(int64_t)k * mat + e] = s;
 }
 
 static void wgrad_config(int ca, int cg, int *wm, int *nt) {
@@ -543,25 +613,25 @@ static void wgrad_config(int ca, int cg, int *wm, int *nt) {
   *nt = n;
 }
 
-static int wgrad_slices(int64_t n_pairs, int ca, int cg, int kvol) {
+// pairs per tile: aim at ~6 blocks per CU over all (tile, M-tile, N-tile) blocks, 128..4096 pairs
+static int wgrad_tile_len(int64_t n_pairs, int ca, int cg, int kvol) {
   int wm, nt;
   wgrad_config(ca, cg, &wm, &nt);
-  int64_t tiles = (int64_t)kvol * ceil_div(ca, 32 * wm) * ceil_div(cg, 32 * nt);
-  static const int target = getenv("FTX_WGRAD_BLOCKS") ? atoi(getenv("FTX_WGRAD_BLOCKS")) : 1536;  // ~6 blocks per CU
-  static const int min_pairs = getenv("FTX_WGRAD_MIN_PAIRS") ? atoi(getenv("FTX_WGRAD_MIN_PAIRS")) : 256;
-  int64_t want = ceil_div(target, tiles);
-  int64_t max_slices = ceil_div(ceil_div(n_pairs, kvol), min_pairs);  // keep >= ~min_pairs pairs per slice
-  if (want > max_slices) want = max_slices;
-  if (want < 1) want = 1;
-  if (want > 64) want = 64;
-  return (int)want;
+  static const int target = getenv("FTX_WGRAD_BLOCKS") ? atoi(getenv("FTX_WGRAD_BLOCKS")) : 1536;
+  int64_t mn_tiles = ceil_div(ca, 32 * wm) * ceil_div(cg, 32 * nt);
+  int64_t want_tiles = ceil_div(target, mn_tiles);
+  int64_t len = ceil_div(ceil_div(n_pairs, want_tiles), WG_BR) * WG_BR;
+  if (len < 128) len = 128;
+  if (len > 4096) len = 4096;
+  return (int)len;
 }
+
+static int64_t wgrad_tiles_ub(int64_t n_pairs, int tile_len, int kvol) { return ceil_div(n_pairs, tile_len) + kvol; }
 
 extern "C" size_t ftx_spconv_pairs_wgrad_workspace_bytes(int64_t n_pairs, int32_t ca, int32_t cg, int32_t kvol) {
   if (n_pairs <= 0 || ca <= 0 || cg <= 0 || kvol <= 0) return 256;
-  int ns = wgrad_slices(n_pairs, ca, cg, kvol);
-  if (ns <= 1) return 256;
-  return sizeof(float) * (size_t)ns * kvol * ca * cg;
+  int len = wgrad_tile_len(n_pairs, ca, cg, kvol);
+  return sizeof(float) * (size_t)wgrad_tiles_ub(n_pairs, len, kvol) * ca * cg;
 }
 
 template <int WM>
@@ -578,38 +648,43 @@ static void launch_wgrad(int nt, dim3 grid, hipStream_t st, const float *A, int6
 extern "C" int ftx_spconv_pairs_wgrad(const float *A, int64_t rows_a, const int32_t *idx_a, const float *G, int64_t rows_g, const int32_t *idx_g,
                                       const int32_t *koff, int64_t n_pairs, int32_t ca, int32_t cg, int32_t kvol, float *dW, void *workspace,
                                       size_t workspace_bytes, void *stream) {
-  FTX_REQUIRE(n_pairs >= 0 && rows_a >= 0 && rows_g >= 0 && kvol >= 1, "ftx_spconv_pairs_wgrad: bad size");
+  FTX_REQUIRE(n_pairs >= 0 && rows_a >= 0 && rows_g >= 0 && kvol >= 1 && kvol <= 64, "ftx_spconv_pairs_wgrad: bad size");
   FTX_REQUIRE(ca >= 4 && ca % 4 == 0 && cg >= 4 && cg % 4 == 0, "ftx_spconv_pairs_wgrad: channels must be multiples of 4 (ca=%d cg=%d)", ca, cg);
   FTX_REQUIRE(dW, "ftx_spconv_pairs_wgrad: null dW");
   hipStream_t st = (hipStream_t)stream;
-  const int64_t elems = (int64_t)kvol * ca * cg;
+  const int64_t mat = (int64_t)ca * cg;
   if (n_pairs == 0) {
-    if (hipMemsetAsync(dW, 0, sizeof(float) * elems, st) != hipSuccess) return check_launch("ftx_spconv_pairs_wgrad memset");
+    if (hipMemsetAsync(dW, 0, sizeof(float) * kvol * mat, st) != hipSuccess) return check_launch("ftx_spconv_pairs_wgrad memset");
     return FTX_OK;
   }
   FTX_REQUIRE(A && G, "ftx_spconv_pairs_wgrad: null pointer");
   const bool dense = (idx_a == nullptr && idx_g == nullptr && koff == nullptr);
   FTX_REQUIRE(dense || (idx_a && idx_g && koff), "ftx_spconv_pairs_wgrad: idx_a, idx_g and koff must be all set or all null (dense rows)");
-  FTX_REQUIRE(!dense || (kvol == 1 && n_pairs <= rows_a && n_pairs <= rows_g && n_pairs < 0x7fffffff), "ftx_spconv_pairs_wgrad: dense mode needs kvol == 1 and n_pairs rows in A and G");
-  const int ns = wgrad_slices(n_pairs, ca, cg, kvol);
-  float *part = dW;
-  if (ns > 1) {
-    size_t need = sizeof(float) * (size_t)ns * elems;
-    if (!workspace || workspace_bytes < need) {
-      set_error("ftx_spconv_pairs_wgrad: workspace %zu < required %zu", workspace_bytes, need);
-      return FTX_EWORKSPACE;
-    }
-    part = (float *)workspace;
+  FTX_REQUIRE(!dense || (kvol == 1 && n_pairs <= rows_a && n_pairs <= rows_g), "ftx_spconv_pairs_wgrad: dense mode needs kvol == 1 and n_pairs rows in A and G");
+  FTX_REQUIRE(n_pairs < 0x7fffffff, "ftx_spconv_pairs_wgrad: too many pairs");
+  const int tile_len = wgrad_tile_len(n_pairs, ca, cg, kvol);
+  const int64_t tiles = wgrad_tiles_ub(n_pairs, tile_len, kvol);
+  size_t need = sizeof(float) * (size_t)tiles * mat;
+  if (!workspace || workspace_bytes < need) {
+    set_error("ftx_spconv_pairs_wgrad: workspace %zu < required %zu", workspace_bytes, need);
+    return FTX_EWORKSPACE;
   }
+  float *part = (float *)workspace;
   int wm, nt;
   wgrad_config(ca, cg, &wm, &nt);
-  dim3 grid((unsigned)(kvol * ns), (unsigned)ceil_div(ca, 32 * wm), (unsigned)ceil_div(cg, 32 * nt));
+  dim3 grid((unsigned)tiles, (unsigned)ceil_div(ca, 32 * wm), (unsigned)ceil_div(cg, 32 * nt));
   if (wm == 1)
-    launch_wgrad<1>(nt, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part, (int)n_pairs);
+    launch_wgrad<1>(nt, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, tile_len, part, (int)n_pairs);
   else if (wm == 2)
-    launch_wgrad<2>(nt, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part, (int)n_pairs);
+    launch_wgrad<2>(nt, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, tile_len, part, (int)n_pairs);
   else
-    launch_wgrad<4>(nt, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part, (int)n_pairs);
-  if (ns > 1) wgrad_reduce_kernel<<<grid_for(elems / 4, 256), 256, 0, st>>>(part, elems, ns, dW);
+    launch_wgrad<4>(nt, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, tile_len, part, (int)n_pairs);
+  const int64_t avg_tiles = tiles / kvol;
+  if (avg_tiles <= 4)
+    wgrad_reduce_kernel<1><<<dim3((unsigned)ceil_div(mat / 4, 256), (unsigned)kvol), 256, 0, st>>>(part, koff, kvol, tile_len, (int)n_pairs, mat, dW);
+  else if (avg_tiles <= 32)
+    wgrad_reduce_kernel<4><<<dim3((unsigned)ceil_div(mat / 4, 64), (unsigned)kvol), 256, 0, st>>>(part, koff, kvol, tile_len, (int)n_pairs, mat, dW);
+  else
+    wgrad_reduce_kernel<16><<<dim3((unsigned)ceil_div(mat / 4, 16), (unsigned)kvol), 256, 0, st>>>(part, koff, kvol, tile_len, (int)n_pairs, mat, dW);
   return check_launch("ftx_spconv_pairs_wgrad");
 }
