@@ -1,6 +1,7 @@
 """Shared pieces of the three fusion models (the reference repeats them per file)."""
 from __future__ import annotations
 
+import torch
 import torch.nn as nn
 
 from .. import functional as spf
@@ -31,3 +32,65 @@ def fused_outputs(dual_head, preds_lidar, preds_image):
 
 def image_branch(num_class, dual_head, backbone_2d_kwargs):
     return Net2DBillinear(num_classes=num_class, dual_head=dual_head, backbone_2d_kwargs=backbone_2d_kwargs)
+
+
+class _Lazy:
+    """Image features handed from the image stream to the LiDAR stream: `get()` makes the calling
+    stream wait for the producer's event (not for the whole image branch)."""
+
+    def __init__(self):
+        self.feats, self.event = None, None
+
+    def set(self, feats):
+        self.feats = feats.detach()          # middle_fusion.py:102 / early_fusion.py:105
+        if feats.is_cuda:
+            self.event = torch.cuda.Event()
+            self.event.record()
+
+    def get(self):
+        if self.feats is None:
+            raise RuntimeError("the image branch did not produce the fused tap (check *_feat_block_number)")
+        if self.event is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self.event)
+            self.feats.record_stream(cur)
+        return self.feats
+
+
+_STREAMS = {}
+
+
+def _branch_streams(device):
+    key = (device.type, device.index)
+    if key not in _STREAMS:
+        _STREAMS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+    return _STREAMS[key]
+
+
+def run_fusion(model, data_dict, lidar_call, overlap=True):
+    """Runs the image branch and the LiDAR branch of a fusion model.
+
+    On the GPU the two branches are issued on two HIP streams: the ViT is a chain of large dense
+    GEMMs, the SPVCNN a long chain of small gather / scatter kernels and host-synchronising index
+    builds; they share nothing until the fusion add, so they overlap (forward and, through
+    autograd's stream tracking, backward).  `lidar_call(lazy_feats)` runs the LiDAR branch."""
+    img = data_dict["img"]
+    lazy = _Lazy()
+    if not (overlap and img.is_cuda):
+        preds_image = model.image_backbone(img=img, img_indices=data_dict["img_indices"], on_middle=lazy.set)
+        return lidar_call(lazy), preds_image
+    cur = torch.cuda.current_stream()
+    s_img, s_lid = _branch_streams(img.device)
+    s_img.wait_stream(cur)
+    s_lid.wait_stream(cur)
+    with torch.cuda.stream(s_img):
+        preds_image = model.image_backbone(img=img, img_indices=data_dict["img_indices"], on_middle=lazy.set)
+    with torch.cuda.stream(s_lid):
+        preds_lidar = lidar_call(lazy)
+    cur.wait_stream(s_img)
+    cur.wait_stream(s_lid)
+    for d in (preds_image, preds_lidar):
+        for v in d.values():
+            if torch.is_tensor(v):
+                v.record_stream(cur)
+    return preds_lidar, preds_image

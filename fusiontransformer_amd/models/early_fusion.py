@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import torch.nn as nn
 
-from ._fusion_common import fused_outputs, heads, image_branch, lidar_preds
+from ._fusion_common import fused_outputs, heads, image_branch, lidar_preds, run_fusion
 from .spvcnn import SPVCNN, BatchNorm, _linear_bn_relu
 
 
@@ -15,7 +15,10 @@ class Net3DSeg(SPVCNN):
 
     def backbone_forward_pass(self, x, img_early_feats):
         # z0.F = z0.F + early_fusion_transform(img_early_feats)  (early_fusion.py:39)
-        return self._backbone(x, fuse_early=_linear_bn_relu(self.early_fusion_transform, img_early_feats))
+        def fuse():
+            feats = img_early_feats.get() if hasattr(img_early_feats, "get") else img_early_feats
+            return _linear_bn_relu(self.early_fusion_transform, feats)
+        return self._backbone(x, fuse_early=fuse)
 
     def forward(self, x, img_early_feats):
         return lidar_preds(self, self.backbone_forward_pass(x, img_early_feats))
@@ -29,7 +32,7 @@ class EarlyFusionTransformer(nn.Module):
         self.image_backbone = image_branch(num_class, dual_head, backbone_2d_kwargs)
 
     def forward(self, data_dict):
-        preds_image = self.image_backbone(img=data_dict["img"], img_indices=data_dict["img_indices"])
         # with middle_feat_block_number = 0 the "middle" tap is the early one (early_fusion.py:101-105)
-        preds_lidar = self.lidar_backbone(x=data_dict["lidar"], img_early_feats=preds_image["img_middle_feats"].detach())
+        preds_lidar, preds_image = run_fusion(self, data_dict, lambda feats: self.lidar_backbone(x=data_dict["lidar"], img_early_feats=feats),
+                                              overlap=getattr(self, "overlap_branches", True))
         return fused_outputs(self.dual_head, preds_lidar, preds_image)

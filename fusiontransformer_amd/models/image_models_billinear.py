@@ -145,15 +145,26 @@ class Net2DBillinear(nn.Module):
         idx, frame = pack_img_indices(img_indices, x.device)
         return spf.lift_gather(grid, idx, frame, self.lift_size[0], self.lift_size[1])
 
-    def forward(self, img, img_indices):
+    def forward(self, img, img_indices, on_middle=None):
+        """reference image_models_billinear.py:128-155.  `on_middle(feats)` is called with the lifted
+        features of the middle tap as soon as that block has run (the LiDAR branch, on another
+        stream, only waits for this and not for the rest of the ViT)."""
         img_indices = pack_img_indices(img_indices, img.device)
         x = self.sample_down(img)
-        backbone_output = self.backbone.forward_blocks(x)
+        middle = {}
+
+        def tap(i, tokens):
+            if self.middle_feat_block_number is not None and str(i) == self.middle_feat_block_number and self.middle_feat_block_number in self.up:
+                middle["feats"] = self.get_img_feats(img_indices, self.middle_feat_block_number, img.shape, {self.middle_feat_block_number: tokens})
+                if on_middle is not None:
+                    on_middle(middle["feats"])
+
+        backbone_output = self.backbone.forward_blocks(x, on_block=tap)
         late_feats = self.get_img_feats(img_indices, self.late_feat_block_number, img.shape, backbone_output)
         x = spf.linear(late_feats, self.linear.weight, self.linear.bias)
         preds = {"img_feats": late_feats, "img_seg_logit": x}
         if self.dual_head:
             preds["img_seg_logit2"] = spf.linear(late_feats, self.linear2.weight, self.linear2.bias)
         if self.middle_feat_block_number:
-            preds["img_middle_feats"] = self.get_img_feats(img_indices, self.middle_feat_block_number, img.shape, backbone_output)
+            preds["img_middle_feats"] = middle["feats"]
         return preds

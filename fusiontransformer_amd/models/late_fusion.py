@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import torch.nn as nn
 
-from ._fusion_common import fused_outputs, heads, image_branch, lidar_preds
+from ._fusion_common import fused_outputs, heads, image_branch, lidar_preds, run_fusion
 from .spvcnn import SPVCNN
 
 
@@ -25,6 +25,6 @@ class LateFusionTransformer(nn.Module):
         self.image_backbone = image_branch(num_class, dual_head, backbone_2d_kwargs)
 
     def forward(self, data_dict):
-        preds_image = self.image_backbone(data_dict["img"], data_dict["img_indices"])
-        preds_lidar = self.lidar_backbone(data_dict["lidar"])
+        preds_lidar, preds_image = run_fusion(self, data_dict, lambda feats: self.lidar_backbone(data_dict["lidar"]),
+                                              overlap=getattr(self, "overlap_branches", True))
         return fused_outputs(self.dual_head, preds_lidar, preds_image)

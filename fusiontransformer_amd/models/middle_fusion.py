@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import torch.nn as nn
 
-from ._fusion_common import fused_outputs, heads, image_branch, lidar_preds
+from ._fusion_common import fused_outputs, heads, image_branch, lidar_preds, run_fusion
 from .spvcnn import SPVCNN, BatchNorm, _linear_bn_relu
 
 
@@ -15,7 +15,11 @@ class Net3DSeg(SPVCNN):
 
     def backbone_forward_pass(self, x, img_middle_feats):
         # z1.F = z1.F + point_transforms[0](z0.F) + middle_fusion_transform(img_middle_feats)  (middle_fusion.py:48)
-        return self._backbone(x, fuse_middle=_linear_bn_relu(self.middle_fusion_transform, img_middle_feats))
+        # img_middle_feats may be a lazy hand-off from the image stream: it is only touched at the fusion point
+        def fuse():
+            feats = img_middle_feats.get() if hasattr(img_middle_feats, "get") else img_middle_feats
+            return _linear_bn_relu(self.middle_fusion_transform, feats)
+        return self._backbone(x, fuse_middle=fuse)
 
     def forward(self, x, img_middle_feats):
         return lidar_preds(self, self.backbone_forward_pass(x, img_middle_feats))
@@ -29,6 +33,6 @@ class MiddleFusionTransformer(nn.Module):
         self.image_backbone = image_branch(num_class, dual_head, backbone_2d_kwargs)
 
     def forward(self, data_dict):
-        preds_image = self.image_backbone(img=data_dict["img"], img_indices=data_dict["img_indices"])
-        preds_lidar = self.lidar_backbone(x=data_dict["lidar"], img_middle_feats=preds_image["img_middle_feats"].detach())
+        preds_lidar, preds_image = run_fusion(self, data_dict, lambda feats: self.lidar_backbone(x=data_dict["lidar"], img_middle_feats=feats),
+                                              overlap=getattr(self, "overlap_branches", True))
         return fused_outputs(self.dual_head, preds_lidar, preds_image)

@@ -208,7 +208,7 @@ class SPVCNN(nn.Module):
         x0 = self._stem(x0)
         z0 = voxel_to_point(x0, z, nearest=False)
         if fuse_early is not None:
-            z0.F = z0.F + fuse_early
+            z0.F = z0.F + (fuse_early() if callable(fuse_early) else fuse_early)
 
         x1 = point_to_voxel(x0, z0)
         x1 = self.stage1(x1)
@@ -218,7 +218,7 @@ class SPVCNN(nn.Module):
         z1 = voxel_to_point(x4, z0)
         z1.F = z1.F + _linear_bn_relu(self.point_transforms[0], z0.F)
         if fuse_middle is not None:
-            z1.F = z1.F + fuse_middle
+            z1.F = z1.F + (fuse_middle() if callable(fuse_middle) else fuse_middle)
 
         y1 = point_to_voxel(x4, z1)
         y1.F = self._drop(y1.F, "y1")

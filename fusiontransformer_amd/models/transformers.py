@@ -132,8 +132,10 @@ class Image2DTransformer(nn.Module):
         for blk in self.blocks:
             blk.attn.attn_impl = impl
 
-    def forward_blocks(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
-        """reference models/transformers.py:16-45: every block's output, cls/dist tokens stripped."""
+    def forward_blocks(self, x: torch.Tensor, on_block=None) -> Dict[str, torch.Tensor]:
+        """reference models/transformers.py:16-45: every block's output, cls/dist tokens stripped.
+        `on_block(i, tokens)` is called as soon as block i's output exists (used to lift the tapped
+        block's features while the remaining blocks are still being issued)."""
         x = self.patch_embed(x)
         cls_token = self.cls_token.expand(x.shape[0], -1, -1)
         if self.dist_token is None:
@@ -150,6 +152,8 @@ class Image2DTransformer(nn.Module):
                 outputs[str(i)] = x[:, self.num_tokens:, :]
             else:
                 outputs[str(i)] = x
+            if on_block is not None:
+                on_block(i, outputs[str(i)])
         return outputs
 
 
