@@ -94,7 +94,8 @@ def check(rc: int, what: str):
 
 
 def stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """Raw hipStream_t of torch's current stream (the C bindings: torch.cuda.current_stream() costs ~9 us)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def ptr(t):

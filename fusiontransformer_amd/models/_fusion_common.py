@@ -67,6 +67,21 @@ def _branch_streams(device):
     return _STREAMS[key]
 
 
+def bump_batchnorm_counters(model):
+    """num_batches_tracked += 1 for every BatchNorm of the model in ONE multi-tensor launch (the
+    per-module add_ is ~60 tiny kernels per step).  Every BatchNorm of these models runs exactly once
+    per training forward, so the counters end up exactly as the per-module increments leave them."""
+    bns = getattr(model, "_ftx_bns", None)
+    if bns is None:
+        bns = [m for m in model.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.track_running_stats and m.num_batches_tracked is not None]
+        for m in bns:
+            m._nbt_external = True
+        object.__setattr__(model, "_ftx_bns", bns)
+    live = [m.num_batches_tracked for m in bns if m.training]
+    if live:
+        torch._foreach_add_(live, 1)
+
+
 def run_fusion(model, data_dict, lidar_call, overlap=True):
     """Runs the image branch and the LiDAR branch of a fusion model.
 
@@ -76,6 +91,8 @@ def run_fusion(model, data_dict, lidar_call, overlap=True):
     autograd's stream tracking, backward).  `lidar_call(lazy_feats)` runs the LiDAR branch."""
     img = data_dict["img"]
     lazy = _Lazy()
+    if model.training:
+        bump_batchnorm_counters(model)
     if not (overlap and img.is_cuda):
         preds_image = model.image_backbone(img=img, img_indices=data_dict["img_indices"], on_middle=lazy.set)
         return lidar_call(lazy), preds_image

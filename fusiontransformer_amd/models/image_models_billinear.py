@@ -56,7 +56,7 @@ class BilinearModule(nn.Module):
         # every pixel), then the nearest pick
         conv, bn = self.stem[0], self.stem[2]
         if conv.in_channels == 3 and conv.out_channels == 3 and (bn.training or not torch.is_grad_enabled() or not conv.weight.requires_grad):
-            if bn.training and bn.track_running_stats:
+            if bn.training and bn.track_running_stats and not getattr(bn, "_nbt_external", False):
                 bn.num_batches_tracked.add_(1)
             conv_w = conv.weight.view(3, 3)
             if x.requires_grad:
@@ -76,7 +76,7 @@ class BilinearModule(nn.Module):
         B, T, E = tokens.shape
         conv, bn = self.stem[0], self.stem[2]
         rows = F.relu(F.linear(tokens.reshape(B * T, E), conv.weight.view(conv.out_channels, E), conv.bias))
-        if bn.training and bn.track_running_stats:
+        if bn.training and bn.track_running_stats and not getattr(bn, "_nbt_external", False):
             bn.num_batches_tracked.add_(1)
         rows = spf.batch_norm(rows, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps)
         return rows.view(B, grid_hw[0], grid_hw[1], conv.out_channels)

@@ -65,7 +65,7 @@ class BatchNorm(nn.BatchNorm1d):
     """spnn.BatchNorm: BatchNorm1d over the voxel rows; `fused` adds the residual and ReLU in the same pass."""
 
     def fused(self, feats, residual=None, relu=False):
-        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None and not getattr(self, "_nbt_external", False):
             self.num_batches_tracked.add_(1)
         return spf.batch_norm(feats, self.weight, self.bias, self.running_mean, self.running_var, self.training,
                               self.momentum, self.eps, residual=residual, relu=relu)
