@@ -158,7 +158,10 @@ def main():
     from fusiontransformer_amd.models.build import build_model
     from fusiontransformer_amd.trainer import TrainStep
 
-    rank, world, local_rank = init_process_group()
+    # FTX_DIST_BACKEND=gloo FTX_FORCE_DEVICE=0 rehearses the N>1 path with several ranks on ONE GPU
+    rank, world, local_rank = init_process_group(os.environ.get("FTX_DIST_BACKEND"))
+    if os.environ.get("FTX_FORCE_DEVICE") is not None:
+        local_rank = int(os.environ["FTX_FORCE_DEVICE"])
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():

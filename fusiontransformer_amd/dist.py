@@ -34,17 +34,17 @@ def init_process_group(backend=None):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(int(os.environ.get("FTX_FORCE_DEVICE", local_rank)))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
 
 class _Bucket:
-    __slots__ = ("params", "flat", "pending", "work", "launched")
+    __slots__ = ("params", "flat", "pending", "work", "launched", "events")
 
     def __init__(self, params, flat):
         self.params, self.flat = params, flat
-        self.pending, self.work, self.launched = len(params), None, False
+        self.pending, self.work, self.launched, self.events = len(params), None, False, []
 
 
 class GradReducer:
@@ -65,6 +65,13 @@ class GradReducer:
         self._build(list(reversed(self.params)))
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._on_grad_ready)
+        # The hooks keep the AccumulateGrad nodes (created on the default stream) alive while the model's
+        # branches run on their own streams; autograd then orders each accumulation after its producer
+        # stream, which is exactly what the bucket events rely on.  The advisory warning about it is noise.
+        try:
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+        except AttributeError:
+            pass
 
     # -- bucket construction -------------------------------------------------
     def _build(self, ordered):
@@ -103,7 +110,7 @@ class GradReducer:
             self._build(order)
             self._rebuilt = True
         for b in self.buckets:
-            b.pending, b.work, b.launched = len(b.params), None, False
+            b.pending, b.work, b.launched, b.events = len(b.params), None, False, []
             b.flat.zero_()   # zero_grad for every gradient of the bucket in one fill
         self.next_to_launch = 0
         self._record = self.step_idx == 0
@@ -113,6 +120,12 @@ class GradReducer:
     def _launch(self, b):
         b.launched = True
         if self.world > 1:
+            if b.flat.is_cuda:
+                # the model runs its two branches on two HIP streams, so a bucket's gradients may have
+                # been accumulated on different streams: order the reduction after every one of them
+                cur = torch.cuda.current_stream()
+                for ev in b.events:
+                    cur.wait_event(ev)
             b.flat.div_(self.world)
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
@@ -126,6 +139,10 @@ class GradReducer:
             self.ready_order.append(p)
         b = self.buckets[self.bucket_of[p]]
         b.pending -= 1
+        if p.is_cuda and self.world > 1:
+            ev = torch.cuda.Event()
+            ev.record()          # on the stream that just accumulated this gradient
+            b.events.append(ev)
         if self._rebuilt:  # overlap only once the bucket order follows the backward
             self._launch_ready_prefix()
 
