@@ -45,7 +45,7 @@ def build_inputs(cfg, batch, shape, rank, device):
     return b, data
 
 
-def spconv_roofline(log):
+def spconv_roofline(log, workload=None):
     """Algorithmic bytes / HIP-event time over the sparse-conv launches of one timed step.
 
     Unit = one (in,out) pair: 4*(ca+co) bytes (gather ca floats + write co floats), plus
@@ -72,10 +72,19 @@ def spconv_roofline(log):
         return None
     achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
     n_conv = sum(v[0] for k, v in per_kind.items() if k != "spconv_reduce")
+    traffic, traffic_note = None, None
+    try:  # HBM bytes of these kernels from the PMC passes committed under profiles/ (same workload)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_spconv.json")))
+        if pmc["workload"] == workload:
+            traffic = int(pmc["fetch_corrected_bytes_per_step"] + pmc["write_bytes_per_step"])
+            traffic_note = ("bytes per step over the same kernels: FETCH_SIZE x2 (gfx950 correction, upper bound for 16-B gathers) + WRITE_SIZE, "
+                            "rocprofv3 --pmc in separate passes, profiles/r01_pmc_hbm_spconv.json")
+    except (OSError, KeyError, ValueError):
+        pass
     return {
         "bound": "hbm", "kernel": "pairs_gemm_kernel + spconv_reduce_kernel + pairs_wgrad_kernel (sparse conv fwd / dgrad / wgrad)",
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-        "traffic": None,
+        "traffic": traffic, "traffic_note": traffic_note,
         "launches": len(log), "convolutions": n_conv, "avg_conv_us": round(1e3 * tot_ms / max(n_conv, 1), 2),
         "algorithmic_bytes_per_step": int(tot_bytes), "useful_tflops": round(tot_flops / (tot_ms * 1e-3) / 1e12, 3),
         "mfma_f32_peak_tflops": MFMA_F32_PEAK_TFLOPS,
@@ -224,7 +233,7 @@ def main():
     if rank == 0:
         log("%.1f ms/step" % (1e3 * elapsed / args.steps))
         frames = args.batch * world * args.steps
-        roof = spconv_roofline(launch_log) if launch_log else None
+        roof = spconv_roofline(launch_log, {"batch": args.batch, "shape": args.shape, "kind": args.kind}) if launch_log else None
         out = {
             "metric": "frames/sec fwd+bwd (SemanticKITTI synth), whole job",
             "value": round(frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
