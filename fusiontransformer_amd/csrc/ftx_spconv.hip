@@ -125,37 +125,42 @@ extern "C" int ftx_kernel_map_pairs(const int32_t *nbr, int64_t n_out, int64_t n
 // ---------------------------------------------------------------------------------------
 constexpr int BK = 32;         // reduction chunk staged per step
 constexpr int AS_STRIDE = 36;  // floats
-constexpr int TILE_P = 128;    // pairs per tile (4 waves x 32)
+constexpr int TILE_P = 128;    // pairs per tile and row-tile count RT: tile = RT x (4 waves x 32 pairs)
 
-template <int NT>
+// NT = 32-column tiles per wave, RT = 32-pair row tiles per wave.  RT = 2 (256-pair tiles) halves the
+// W[k] traffic, the B-operand LDS reads and the barriers per MFMA; used when every offset has
+// enough pairs that the padding of its last tile does not matter.
+template <int NT, int RT>
 __global__ __launch_bounds__(256) void pairs_gemm_kernel(const float *__restrict__ A, int64_t rows_a, const int32_t *__restrict__ gather,
                                                          const float *__restrict__ W, int w_transposed, const int32_t *__restrict__ koff,
                                                          int ca, int co, int kvol, float *__restrict__ tmp, const float *__restrict__ bias,
                                                          int64_t n_dense) {
   // gather == nullptr: dense mode, tmp[r,:] = A[r,:] @ W (+ bias) for r < n_dense (kvol = 1)
+  constexpr int TILE = TILE_P * RT;
   constexpr int BN = 32 * NT;
   constexpr int BS_STRIDE = BN + 4;
   constexpr int B_VEC = BK * BN / 4;           // float4 per W chunk
   constexpr int B_PASSES = (B_VEC + 255) / 256;
+  constexpr int A_PASSES = 4 * RT;
 
-  __shared__ __attribute__((aligned(16))) float As[TILE_P * AS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float As[TILE * AS_STRIDE];
   __shared__ __attribute__((aligned(16))) float Bs[BK * BS_STRIDE];
   __shared__ int s_tile[3];
 
   const int tid = threadIdx.x;
   if (gather == nullptr) {
     if (tid == 0) {
-      int64_t left = n_dense - (int64_t)blockIdx.x * TILE_P;
+      int64_t left = n_dense - (int64_t)blockIdx.x * TILE;
       s_tile[0] = left > 0 ? 0 : -1;
-      s_tile[1] = blockIdx.x * TILE_P;
-      s_tile[2] = left > TILE_P ? TILE_P : (int)left;
+      s_tile[1] = blockIdx.x * TILE;
+      s_tile[2] = left > TILE ? TILE : (int)left;
     }
   } else if (tid < 64) {
     // tile -> (offset, first pair, pair count): wave 0 scans the per-offset tile counts
     const int lane0 = tid;
     const int b = blockIdx.x;
     int c = (lane0 < kvol) ? koff[lane0 + 1] - koff[lane0] : 0;
-    int nt = (c + TILE_P - 1) / TILE_P;
+    int nt = (c + TILE - 1) / TILE;
     int incl = nt;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -167,10 +172,10 @@ __global__ __launch_bounds__(256) void pairs_gemm_kernel(const float *__restrict
     unsigned long long m = __ballot(mine);
     if (mine) {
       int t = b - excl;
-      int left = c - t * TILE_P;
+      int left = c - t * TILE;
       s_tile[0] = lane0;
-      s_tile[1] = koff[lane0] + t * TILE_P;
-      s_tile[2] = left > TILE_P ? TILE_P : left;
+      s_tile[1] = koff[lane0] + t * TILE;
+      s_tile[2] = left > TILE ? TILE : left;
     }
     if (m == 0ull && lane0 == 0) s_tile[0] = -1;
   }
@@ -184,9 +189,9 @@ __global__ __launch_bounds__(256) void pairs_gemm_kernel(const float *__restrict
   const int n0 = blockIdx.y * BN;
   const int arow = tid >> 3, acol = (tid & 7) * 4;
 
-  int32_t src[4];
+  int32_t src[A_PASSES];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < A_PASSES; ++p) {
     int r = p * 32 + arow;
     int32_t s = -1;
     if (r < cnt) s = gather ? gather[p0 + r] : p0 + r;
@@ -195,16 +200,18 @@ __global__ __launch_bounds__(256) void pairs_gemm_kernel(const float *__restrict
   }
   const float *Wk = W + (int64_t)k * ca * co;
 
-  f32x16 acc[NT];
+  f32x16 acc[RT][NT];
 #pragma unroll
-  for (int j = 0; j < NT; ++j)
+  for (int r = 0; r < RT; ++r)
 #pragma unroll
-    for (int g = 0; g < 16; ++g) acc[j][g] = 0.f;
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[r][j][g] = 0.f;
 
-  float4 ra[4], rb[B_PASSES];
+  float4 ra[A_PASSES], rb[B_PASSES];
   auto load_chunk = [&](int c0) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < A_PASSES; ++p) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (src[p] >= 0 && c0 + acol < ca) v = *(const float4 *)&A[(int64_t)src[p] * ca + c0 + acol];
       ra[p] = v;
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(256) void pairs_gemm_kernel(const float *__restrict
   };
   auto store_chunk = [&]() {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) *(float4 *)&As[(p * 32 + arow) * AS_STRIDE + acol] = ra[p];
+    for (int p = 0; p < A_PASSES; ++p) *(float4 *)&As[(p * 32 + arow) * AS_STRIDE + acol] = ra[p];
 #pragma unroll
     for (int q = 0; q < B_PASSES; ++q) {
       int e = q * 256 + tid;
@@ -251,18 +258,23 @@ __global__ __launch_bounds__(256) void pairs_gemm_kernel(const float *__restrict
     store_chunk();
     __syncthreads();
     if (c0 + BK < ca) load_chunk(c0 + BK);  // next chunk's global loads fly under the MFMAs
-    const float *arow_p = &As[(wave * 32 + l31) * AS_STRIDE + 4 * half];
+    const float *arow_p = &As[(wave * 32 * RT + l31) * AS_STRIDE + 4 * half];
     const float *bcol_p = &Bs[(4 * half) * BS_STRIDE + l31];
 #pragma unroll
     for (int t = 0; t < BK / 8; ++t) {
-      float4 a = *(const float4 *)(arow_p + 8 * t);
-      float av[4] = {a.x, a.y, a.z, a.w};
+      float av[RT][4];
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        float4 a = *(const float4 *)(arow_p + r * 32 * AS_STRIDE + 8 * t);
+        av[r][0] = a.x; av[r][1] = a.y; av[r][2] = a.z; av[r][3] = a.w;
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           float b = bcol_p[(8 * t + s) * BS_STRIDE + j * 32];
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b, acc[j], 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < RT; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r][s], b, acc[r][j], 0, 0, 0);
         }
       }
     }
@@ -271,36 +283,60 @@ __global__ __launch_bounds__(256) void pairs_gemm_kernel(const float *__restrict
 
   // ---- tmp rows of this tile are contiguous: each 32-lane half stores 128 bytes per register
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    int col = n0 + j * 32 + l31;
-    if (col < co) {
-      const float bv = bias ? bias[col] : 0.f;
+  for (int r = 0; r < RT; ++r)
 #pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        int r = wave * 32 + (g & 3) + 8 * (g >> 2) + 4 * half;
-        if (r < cnt) tmp[(int64_t)(p0 + r) * co + col] = acc[j][g] + bv;
+    for (int j = 0; j < NT; ++j) {
+      int col = n0 + j * 32 + l31;
+      if (col < co) {
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          int row = wave * 32 * RT + r * 32 + (g & 3) + 8 * (g >> 2) + 4 * half;
+          if (row < cnt) tmp[(int64_t)(p0 + row) * co + col] = acc[r][j][g] + bv;
+        }
       }
     }
+}
+
+template <int RT>
+static void launch_pairs_gemm(int nt, dim3 grid, hipStream_t st, const float *A, int64_t rows_a, const int32_t *gather, const float *W, int wT,
+                              const int32_t *koff, int ca, int co, int kvol, float *tmp, const float *bias, int64_t n_dense) {
+  switch (nt) {
+    case 1: pairs_gemm_kernel<1, RT><<<grid, 256, 0, st>>>(A, rows_a, gather, W, wT, koff, ca, co, kvol, tmp, bias, n_dense); break;
+    case 2: pairs_gemm_kernel<2, RT><<<grid, 256, 0, st>>>(A, rows_a, gather, W, wT, koff, ca, co, kvol, tmp, bias, n_dense); break;
+    case 3: pairs_gemm_kernel<3, RT><<<grid, 256, 0, st>>>(A, rows_a, gather, W, wT, koff, ca, co, kvol, tmp, bias, n_dense); break;
+    default: pairs_gemm_kernel<4, RT><<<grid, 256, 0, st>>>(A, rows_a, gather, W, wT, koff, ca, co, kvol, tmp, bias, n_dense); break;
   }
+}
+
+static int gemm_nt(int co) {
+  int nt = co >= 128 ? 4 : (co + 31) / 32;
+  if (co > 128 && co % 96 == 0 && co % 128 != 0) nt = 3;
+  return nt;
+}
+
+// Measured on MI355X (profiles/r01_spconv_layer_micro.txt workload): 256-pair tiles (RT = 2) are 5-30 % SLOWER
+// than 128-pair tiles on every layer -- the extra accumulators cut occupancy to 1-2 waves per SIMD and
+// the kernel is latency-, not W-traffic-bound.  RT = 2 stays selectable (FTX_GEMM_RT=2) as a tuning aid.
+static int gemm_rt(int64_t n_pairs, int kvol, int ca, int co) {
+  static const int forced = getenv("FTX_GEMM_RT") ? atoi(getenv("FTX_GEMM_RT")) : 0;
+  return forced == 2 ? 2 : 1;
 }
 
 extern "C" int ftx_spconv_pairs_gemm(const float *A, int64_t rows_a, const int32_t *gather, const float *W, int32_t w_transposed,
                                      const int32_t *koff, int64_t n_pairs, int32_t ca, int32_t co, int32_t kvol, float *tmp, void *stream) {
-  FTX_REQUIRE(n_pairs >= 0 && rows_a >= 0 && kvol >= 1, "ftx_spconv_pairs_gemm: bad size");
+  FTX_REQUIRE(n_pairs >= 0 && rows_a >= 0 && kvol >= 1 && kvol <= 64, "ftx_spconv_pairs_gemm: bad size");
   FTX_REQUIRE(ca >= 4 && ca % 4 == 0 && co >= 4 && co % 4 == 0, "ftx_spconv_pairs_gemm: channels must be multiples of 4 (ca=%d co=%d)", ca, co);
   if (n_pairs == 0) return FTX_OK;
   FTX_REQUIRE(A && gather && W && koff && tmp, "ftx_spconv_pairs_gemm: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  const unsigned tiles_ub = (unsigned)(ceil_div(n_pairs, TILE_P) + kvol);  // sum_k ceil(cnt_k/128) <= P/128 + kvol
-  int nt = co >= 128 ? 4 : (co + 31) / 32;
-  if (co > 128 && co % 96 == 0 && co % 128 != 0) nt = 3;
+  const int nt = gemm_nt(co), rt = gemm_rt(n_pairs, kvol, ca, co);
+  const unsigned tiles_ub = (unsigned)(ceil_div(n_pairs, TILE_P * rt) + kvol);  // sum_k ceil(cnt_k/tile) <= P/tile + kvol
   dim3 grid(tiles_ub, (unsigned)ceil_div(co, 32 * nt));
-  switch (nt) {
-    case 1: pairs_gemm_kernel<1><<<grid, 256, 0, st>>>(A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0); break;
-    case 2: pairs_gemm_kernel<2><<<grid, 256, 0, st>>>(A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0); break;
-    case 3: pairs_gemm_kernel<3><<<grid, 256, 0, st>>>(A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0); break;
-    default: pairs_gemm_kernel<4><<<grid, 256, 0, st>>>(A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0); break;
-  }
+  if (rt == 2)
+    launch_pairs_gemm<2>(nt, grid, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0);
+  else
+    launch_pairs_gemm<1>(nt, grid, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0);
   return check_launch("ftx_spconv_pairs_gemm");
 }
 
@@ -314,15 +350,12 @@ extern "C" int ftx_rows_gemm(const float *A, int64_t n, const float *W, int32_t 
   if (n == 0) return FTX_OK;
   FTX_REQUIRE(A && W && out, "ftx_rows_gemm: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  int nt = co >= 128 ? 4 : (co + 31) / 32;
-  if (co > 128 && co % 96 == 0 && co % 128 != 0) nt = 3;
-  dim3 grid((unsigned)ceil_div(n, TILE_P), (unsigned)ceil_div(co, 32 * nt));
-  switch (nt) {
-    case 1: pairs_gemm_kernel<1><<<grid, 256, 0, st>>>(A, n, nullptr, W, w_transposed, nullptr, ca, co, 1, out, bias, n); break;
-    case 2: pairs_gemm_kernel<2><<<grid, 256, 0, st>>>(A, n, nullptr, W, w_transposed, nullptr, ca, co, 1, out, bias, n); break;
-    case 3: pairs_gemm_kernel<3><<<grid, 256, 0, st>>>(A, n, nullptr, W, w_transposed, nullptr, ca, co, 1, out, bias, n); break;
-    default: pairs_gemm_kernel<4><<<grid, 256, 0, st>>>(A, n, nullptr, W, w_transposed, nullptr, ca, co, 1, out, bias, n); break;
-  }
+  const int nt = gemm_nt(co), rt = gemm_rt(n, 1, ca, co);
+  dim3 grid((unsigned)ceil_div(n, TILE_P * rt), (unsigned)ceil_div(co, 32 * nt));
+  if (rt == 2)
+    launch_pairs_gemm<2>(nt, grid, st, A, n, nullptr, W, w_transposed, nullptr, ca, co, 1, out, bias, n);
+  else
+    launch_pairs_gemm<1>(nt, grid, st, A, n, nullptr, W, w_transposed, nullptr, ca, co, 1, out, bias, n);
   return check_launch("ftx_rows_gemm");
 }
 
