@@ -109,13 +109,22 @@ __device__ inline void tile_prefetch_o(const float *o, int b, int hd, int t0, in
 }
 
 // ---------------------------------------------------------------------------------------
-// forward: block = (128 queries, head, batch); wave = 32 queries; loop over 32-key tiles
+// All three kernels: block = 128 queries (or keys) x SPLIT groups of 4 waves.  Group g walks the inner
+// tiles g, g+SPLIT, ... with its own LDS tile pair and the groups' partial results are merged through
+// LDS at the end.  578 tokens give only 912 (32-row) wave-tiles per layer for 1024 SIMDs; SPLIT = 2
+// puts two waves on every SIMD so one computes while the other waits on LDS / global loads.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float *__restrict__ qkv, int T, int nh, float scale, float *__restrict__ out,
-                                                       float *__restrict__ lse) {
-  __shared__ __attribute__((aligned(16))) float Ks[32 * TS];
-  __shared__ __attribute__((aligned(16))) float Vs[32 * TS];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+constexpr int ATT_SPLIT = 2;
+
+// forward: wave = 32 queries; loop over 32-key tiles
+template <int SPLIT>
+__global__ __launch_bounds__(256 * SPLIT) void attn_fwd_kernel(const float *__restrict__ qkv, int T, int nh, float scale,
+                                                               float *__restrict__ out, float *__restrict__ lse) {
+  __shared__ __attribute__((aligned(16))) float Ks[SPLIT][32 * TS];
+  __shared__ __attribute__((aligned(16))) float Vs[SPLIT][32 * TS];
+  __shared__ float comb[SPLIT > 1 ? 4 * 34 * 64 : 1];
+  const int tid = threadIdx.x & 255, grp = threadIdx.x >> 8;
+  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int hd = blockIdx.y, b = blockIdx.z;
   const int q = blockIdx.x * 128 + wave * 32 + l31;   // this lane's query (the accumulator column)
   const bool qv = q < T;
@@ -130,54 +139,86 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float *__restrict__
   float m = -INFINITY, l = 0.f;
 
   const int ntiles = (T + 31) / 32;
+  const int iters = (ntiles + SPLIT - 1) / SPLIT;
   float4 rk[2], rv[2];
-  tile_prefetch(qkv, b, hd, 1, 0, T, nh, tid, rk);
-  tile_prefetch(qkv, b, hd, 2, 0, T, nh, tid, rv);
-  for (int kt = 0; kt < ntiles; ++kt) {
-    tile_store(Ks, tid, rk);
-    tile_store(Vs, tid, rv);
+  tile_prefetch(qkv, b, hd, 1, grp * 32, T, nh, tid, rk);
+  tile_prefetch(qkv, b, hd, 2, grp * 32, T, nh, tid, rv);
+  for (int it = 0; it < iters; ++it) {
+    const int kt = it * SPLIT + grp;
+    tile_store(Ks[grp], tid, rk);
+    tile_store(Vs[grp], tid, rv);
     __syncthreads();
-    if (kt + 1 < ntiles) {
-      tile_prefetch(qkv, b, hd, 1, (kt + 1) * 32, T, nh, tid, rk);
-      tile_prefetch(qkv, b, hd, 2, (kt + 1) * 32, T, nh, tid, rv);
+    if (it + 1 < iters) {
+      tile_prefetch(qkv, b, hd, 1, (kt + SPLIT) * 32, T, nh, tid, rk);
+      tile_prefetch(qkv, b, hd, 2, (kt + SPLIT) * 32, T, nh, tid, rv);
     }
-    // S^T[key][q]: rows = keys of this tile, column = this lane's query
-    f32x16 st;
+    if (kt < ntiles) {
+      // S^T[key][q]: rows = keys of this tile, column = this lane's query
+      f32x16 st;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) st[g] = 0.f;
-    mfma_lds_x_frag(Ks, l31, h, qf, st);
-    float mx = -INFINITY;
+      for (int g = 0; g < 16; ++g) st[g] = 0.f;
+      mfma_lds_x_frag(Ks[grp], l31, h, qf, st);
+      float mx = -INFINITY;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      float s = st[g] * sl2;
-      if (kt * 32 + acc_row(g, h) >= T) s = -INFINITY;
-      st[g] = s;
-      mx = fmaxf(mx, s);
+      for (int g = 0; g < 16; ++g) {
+        float sv = st[g] * sl2;
+        if (kt * 32 + acc_row(g, h) >= T) sv = -INFINITY;
+        st[g] = sv;
+        mx = fmaxf(mx, sv);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));     // the other 16 keys of the tile live in the partner half
+      const float m_new = fmaxf(m, mx);
+      const float alpha = exp2f(m - m_new);
+      float rs = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        float p = exp2f(st[g] - m_new);
+        st[g] = p;
+        rs += p;
+      }
+      rs += __shfl_xor(rs, 32, 64);
+      l = l * alpha + rs;
+      m = m_new;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        o0[g] *= alpha;
+        o1[g] *= alpha;
+      }
+      // O^T[dv][q] += sum_key V[key][dv] * P^T[key][q]
+      mfma_ldsT_x_acc(Vs[grp], 0, l31, h, st, o0);
+      mfma_ldsT_x_acc(Vs[grp], 32, l31, h, st, o1);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));     // the other 16 keys of the tile live in the partner half
-    const float m_new = fmaxf(m, mx);
-    const float alpha = exp2f(m - m_new);
-    float rs = 0.f;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      float p = exp2f(st[g] - m_new);
-      st[g] = p;
-      rs += p;
-    }
-    rs += __shfl_xor(rs, 32, 64);
-    l = l * alpha + rs;
-    m = m_new;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      o0[g] *= alpha;
-      o1[g] *= alpha;
-    }
-    // O^T[dv][q] += sum_key V[key][dv] * P^T[key][q]
-    mfma_ldsT_x_acc(Vs, 0, l31, h, st, o0);
-    mfma_ldsT_x_acc(Vs, 32, l31, h, st, o1);
     __syncthreads();
   }
-  if (qv) {
+  if (SPLIT > 1) {   // merge the groups' (m, l, O) in group order
+    for (int r = 1; r < SPLIT; ++r) {
+      float *cw = comb + wave * 34 * 64 + lane;
+      if (grp == r) {
+        cw[0] = m;
+        cw[64] = l;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          cw[(2 + g) * 64] = o0[g];
+          cw[(18 + g) * 64] = o1[g];
+        }
+      }
+      __syncthreads();
+      if (grp == 0) {
+        const float m1 = cw[0], l1 = cw[64];
+        const float mt = fmaxf(m, m1);
+        const float a0 = exp2f(m - mt), a1 = (m1 == -INFINITY) ? 0.f : exp2f(m1 - mt);
+        l = l * a0 + l1 * a1;
+        m = mt;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          o0[g] = o0[g] * a0 + cw[(2 + g) * 64] * a1;
+          o1[g] = o1[g] * a0 + cw[(18 + g) * 64] * a1;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (qv && grp == 0) {
     const float inv = 1.f / l;
     float *op = out + (((int64_t)b * T + q) * nh + hd) * HD;
 #pragma unroll
@@ -213,14 +254,40 @@ __global__ void attn_delta_kernel(const float *__restrict__ o, const float *__re
   }
 }
 
-// dK, dV: block = (128 keys, head, batch); wave = 32 keys; loop over 32-query tiles
-__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float *__restrict__ qkv, const float *__restrict__ go,
-                                                          const float *__restrict__ lse, const float *__restrict__ delta, int T, int nh,
-                                                          float scale, float *__restrict__ gqkv) {
-  __shared__ __attribute__((aligned(16))) float Qs[32 * TS];
-  __shared__ __attribute__((aligned(16))) float Gs[32 * TS];
-  __shared__ float s_lse[32], s_delta[32];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+// Sum the groups' accumulator tiles (NREG registers per lane) into group 0, in group order.
+template <int SPLIT, int NTILES>
+__device__ inline void merge_sum(float *comb, int grp, int wave, int lane, f32x16 (&acc)[NTILES]) {
+  if (SPLIT == 1) return;
+  for (int r = 1; r < SPLIT; ++r) {
+    float *cw = comb + wave * (16 * NTILES) * 64 + lane;
+    if (grp == r) {
+#pragma unroll
+      for (int t = 0; t < NTILES; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) cw[(t * 16 + g) * 64] = acc[t][g];
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+      for (int t = 0; t < NTILES; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[t][g] += cw[(t * 16 + g) * 64];
+    }
+    __syncthreads();
+  }
+}
+
+// dK, dV: wave = 32 keys; loop over 32-query tiles
+template <int SPLIT>
+__global__ __launch_bounds__(256 * SPLIT) void attn_bwd_kv_kernel(const float *__restrict__ qkv, const float *__restrict__ go,
+                                                                  const float *__restrict__ lse, const float *__restrict__ delta, int T,
+                                                                  int nh, float scale, float *__restrict__ gqkv) {
+  __shared__ __attribute__((aligned(16))) float Qs[SPLIT][32 * TS];
+  __shared__ __attribute__((aligned(16))) float Gs[SPLIT][32 * TS];
+  __shared__ float s_lse[SPLIT][32], s_delta[SPLIT][32];
+  __shared__ float comb[SPLIT > 1 ? 4 * 64 * 64 : 1];
+  const int tid = threadIdx.x & 255, grp = threadIdx.x >> 8;
+  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int hd = blockIdx.y, b = blockIdx.z;
   const int key = blockIdx.x * 128 + wave * 32 + l31;   // accumulator column = this lane's key
   const bool kv = key < T;
@@ -230,69 +297,79 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float *__restric
   load_frag(qkv_row(qkv, b, kv ? key : 0, 1, hd, T, nh), h, kv, kf);
   load_frag(qkv_row(qkv, b, kv ? key : 0, 2, hd, T, nh), h, kv, vf);
 
-  f32x16 dv0, dv1, dk0, dk1;
+  f32x16 acc[4];   // dV^T tile 0/1, dK^T tile 0/1
 #pragma unroll
-  for (int g = 0; g < 16; ++g) dv0[g] = dv1[g] = dk0[g] = dk1[g] = 0.f;
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
 
   const int ntiles = (T + 31) / 32;
+  const int iters = (ntiles + SPLIT - 1) / SPLIT;
   float4 rq[2], rg[2];
-  tile_prefetch(qkv, b, hd, 0, 0, T, nh, tid, rq);
-  tile_prefetch_o(go, b, hd, 0, T, nh, tid, rg);
-  for (int qt = 0; qt < ntiles; ++qt) {
-    tile_store(Qs, tid, rq);
-    tile_store(Gs, tid, rg);
+  tile_prefetch(qkv, b, hd, 0, grp * 32, T, nh, tid, rq);
+  tile_prefetch_o(go, b, hd, grp * 32, T, nh, tid, rg);
+  for (int it = 0; it < iters; ++it) {
+    const int qt = it * SPLIT + grp;
+    tile_store(Qs[grp], tid, rq);
+    tile_store(Gs[grp], tid, rg);
     if (tid < 32) {
       int t = qt * 32 + tid;
-      s_lse[tid] = t < T ? lse[((int64_t)b * nh + hd) * T + t] * LOG2E : 0.f;
-      s_delta[tid] = t < T ? delta[((int64_t)b * nh + hd) * T + t] : 0.f;
+      s_lse[grp][tid] = t < T ? lse[((int64_t)b * nh + hd) * T + t] * LOG2E : 0.f;
+      s_delta[grp][tid] = t < T ? delta[((int64_t)b * nh + hd) * T + t] : 0.f;
     }
     __syncthreads();
-    if (qt + 1 < ntiles) {
-      tile_prefetch(qkv, b, hd, 0, (qt + 1) * 32, T, nh, tid, rq);
-      tile_prefetch_o(go, b, hd, (qt + 1) * 32, T, nh, tid, rg);
+    if (it + 1 < iters) {
+      tile_prefetch(qkv, b, hd, 0, (qt + SPLIT) * 32, T, nh, tid, rq);
+      tile_prefetch_o(go, b, hd, (qt + SPLIT) * 32, T, nh, tid, rg);
     }
-    // S[q][key] and dP[q][key]: rows = queries of the tile, column = this lane's key
-    f32x16 s, dp;
+    if (qt < ntiles) {
+      // S[q][key] and dP[q][key]: rows = queries of the tile, column = this lane's key
+      f32x16 s, dp;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) s[g] = dp[g] = 0.f;
-    mfma_lds_x_frag(Qs, l31, h, kf, s);
-    mfma_lds_x_frag(Gs, l31, h, vf, dp);
+      for (int g = 0; g < 16; ++g) s[g] = dp[g] = 0.f;
+      mfma_lds_x_frag(Qs[grp], l31, h, kf, s);
+      mfma_lds_x_frag(Gs[grp], l31, h, vf, dp);
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      int r = acc_row(g, h);
-      bool ok = kv && (qt * 32 + r < T);
-      float p = ok ? exp2f(s[g] * sl2 - s_lse[r]) : 0.f;
-      s[g] = p;                                       // P
-      dp[g] = p * (dp[g] - s_delta[r]) * scale;        // dS
+      for (int g = 0; g < 16; ++g) {
+        int r = acc_row(g, h);
+        bool ok = kv && (qt * 32 + r < T);
+        float p = ok ? exp2f(s[g] * sl2 - s_lse[grp][r]) : 0.f;
+        s[g] = p;                                            // P
+        dp[g] = p * (dp[g] - s_delta[grp][r]) * scale;        // dS
+      }
+      // dV^T[dv][key] += sum_q dO[q][dv] P[q][key];  dK^T[d][key] += sum_q Q[q][d] dS[q][key]
+      mfma_ldsT_x_acc(Gs[grp], 0, l31, h, s, acc[0]);
+      mfma_ldsT_x_acc(Gs[grp], 32, l31, h, s, acc[1]);
+      mfma_ldsT_x_acc(Qs[grp], 0, l31, h, dp, acc[2]);
+      mfma_ldsT_x_acc(Qs[grp], 32, l31, h, dp, acc[3]);
     }
-    // dV^T[dv][key] += sum_q dO[q][dv] P[q][key];  dK^T[d][key] += sum_q Q[q][d] dS[q][key]
-    mfma_ldsT_x_acc(Gs, 0, l31, h, s, dv0);
-    mfma_ldsT_x_acc(Gs, 32, l31, h, s, dv1);
-    mfma_ldsT_x_acc(Qs, 0, l31, h, dp, dk0);
-    mfma_ldsT_x_acc(Qs, 32, l31, h, dp, dk1);
     __syncthreads();
   }
-  if (kv) {
+  merge_sum<SPLIT, 4>(comb, grp, wave, lane, acc);
+  if (kv && grp == 0) {
     float *kp = gqkv + ((((int64_t)b * T + key) * 3 + 1) * nh + hd) * HD;
     float *vp = gqkv + ((((int64_t)b * T + key) * 3 + 2) * nh + hd) * HD;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       int r = acc_row(4 * g4, h);
-      *(float4 *)(kp + r) = make_float4(dk0[4 * g4], dk0[4 * g4 + 1], dk0[4 * g4 + 2], dk0[4 * g4 + 3]);
-      *(float4 *)(kp + 32 + r) = make_float4(dk1[4 * g4], dk1[4 * g4 + 1], dk1[4 * g4 + 2], dk1[4 * g4 + 3]);
-      *(float4 *)(vp + r) = make_float4(dv0[4 * g4], dv0[4 * g4 + 1], dv0[4 * g4 + 2], dv0[4 * g4 + 3]);
-      *(float4 *)(vp + 32 + r) = make_float4(dv1[4 * g4], dv1[4 * g4 + 1], dv1[4 * g4 + 2], dv1[4 * g4 + 3]);
+      *(float4 *)(vp + r) = make_float4(acc[0][4 * g4], acc[0][4 * g4 + 1], acc[0][4 * g4 + 2], acc[0][4 * g4 + 3]);
+      *(float4 *)(vp + 32 + r) = make_float4(acc[1][4 * g4], acc[1][4 * g4 + 1], acc[1][4 * g4 + 2], acc[1][4 * g4 + 3]);
+      *(float4 *)(kp + r) = make_float4(acc[2][4 * g4], acc[2][4 * g4 + 1], acc[2][4 * g4 + 2], acc[2][4 * g4 + 3]);
+      *(float4 *)(kp + 32 + r) = make_float4(acc[3][4 * g4], acc[3][4 * g4 + 1], acc[3][4 * g4 + 2], acc[3][4 * g4 + 3]);
     }
   }
 }
 
-// dQ: block = (128 queries, head, batch); wave = 32 queries; loop over 32-key tiles
-__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float *__restrict__ qkv, const float *__restrict__ go,
-                                                         const float *__restrict__ lse, const float *__restrict__ delta, int T, int nh,
-                                                         float scale, float *__restrict__ gqkv) {
-  __shared__ __attribute__((aligned(16))) float Ks[32 * TS];
-  __shared__ __attribute__((aligned(16))) float Vs[32 * TS];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+// dQ: wave = 32 queries; loop over 32-key tiles
+template <int SPLIT>
+__global__ __launch_bounds__(256 * SPLIT) void attn_bwd_q_kernel(const float *__restrict__ qkv, const float *__restrict__ go,
+                                                                 const float *__restrict__ lse, const float *__restrict__ delta, int T,
+                                                                 int nh, float scale, float *__restrict__ gqkv) {
+  __shared__ __attribute__((aligned(16))) float Ks[SPLIT][32 * TS];
+  __shared__ __attribute__((aligned(16))) float Vs[SPLIT][32 * TS];
+  __shared__ float comb[SPLIT > 1 ? 4 * 32 * 64 : 1];
+  const int tid = threadIdx.x & 255, grp = threadIdx.x >> 8;
+  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int hd = blockIdx.y, b = blockIdx.z;
   const int q = blockIdx.x * 128 + wave * 32 + l31;
   const bool qv = q < T;
@@ -304,46 +381,51 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float *__restrict
   const float my_lse = qv ? lse[((int64_t)b * nh + hd) * T + q] * LOG2E : 0.f;
   const float my_delta = qv ? delta[((int64_t)b * nh + hd) * T + q] : 0.f;
 
-  f32x16 dq0, dq1;
+  f32x16 acc[2];
 #pragma unroll
-  for (int g = 0; g < 16; ++g) dq0[g] = dq1[g] = 0.f;
+  for (int g = 0; g < 16; ++g) acc[0][g] = acc[1][g] = 0.f;
 
   const int ntiles = (T + 31) / 32;
+  const int iters = (ntiles + SPLIT - 1) / SPLIT;
   float4 rk[2], rv[2];
-  tile_prefetch(qkv, b, hd, 1, 0, T, nh, tid, rk);
-  tile_prefetch(qkv, b, hd, 2, 0, T, nh, tid, rv);
-  for (int kt = 0; kt < ntiles; ++kt) {
-    tile_store(Ks, tid, rk);
-    tile_store(Vs, tid, rv);
+  tile_prefetch(qkv, b, hd, 1, grp * 32, T, nh, tid, rk);
+  tile_prefetch(qkv, b, hd, 2, grp * 32, T, nh, tid, rv);
+  for (int it = 0; it < iters; ++it) {
+    const int kt = it * SPLIT + grp;
+    tile_store(Ks[grp], tid, rk);
+    tile_store(Vs[grp], tid, rv);
     __syncthreads();
-    if (kt + 1 < ntiles) {
-      tile_prefetch(qkv, b, hd, 1, (kt + 1) * 32, T, nh, tid, rk);
-      tile_prefetch(qkv, b, hd, 2, (kt + 1) * 32, T, nh, tid, rv);
+    if (it + 1 < iters) {
+      tile_prefetch(qkv, b, hd, 1, (kt + SPLIT) * 32, T, nh, tid, rk);
+      tile_prefetch(qkv, b, hd, 2, (kt + SPLIT) * 32, T, nh, tid, rv);
     }
-    // S^T[key][q], dP^T[key][q]
-    f32x16 st, dpt;
+    if (kt < ntiles) {
+      // S^T[key][q], dP^T[key][q]
+      f32x16 st, dpt;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) st[g] = dpt[g] = 0.f;
-    mfma_lds_x_frag(Ks, l31, h, qf, st);
-    mfma_lds_x_frag(Vs, l31, h, gf, dpt);
+      for (int g = 0; g < 16; ++g) st[g] = dpt[g] = 0.f;
+      mfma_lds_x_frag(Ks[grp], l31, h, qf, st);
+      mfma_lds_x_frag(Vs[grp], l31, h, gf, dpt);
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      bool ok = qv && (kt * 32 + acc_row(g, h) < T);
-      float p = ok ? exp2f(st[g] * sl2 - my_lse) : 0.f;
-      dpt[g] = p * (dpt[g] - my_delta) * scale;   // dS^T
+      for (int g = 0; g < 16; ++g) {
+        bool ok = qv && (kt * 32 + acc_row(g, h) < T);
+        float p = ok ? exp2f(st[g] * sl2 - my_lse) : 0.f;
+        dpt[g] = p * (dpt[g] - my_delta) * scale;   // dS^T
+      }
+      // dQ^T[d][q] += sum_key K[key][d] dS^T[key][q]
+      mfma_ldsT_x_acc(Ks[grp], 0, l31, h, dpt, acc[0]);
+      mfma_ldsT_x_acc(Ks[grp], 32, l31, h, dpt, acc[1]);
     }
-    // dQ^T[d][q] += sum_key K[key][d] dS^T[key][q]
-    mfma_ldsT_x_acc(Ks, 0, l31, h, dpt, dq0);
-    mfma_ldsT_x_acc(Ks, 32, l31, h, dpt, dq1);
     __syncthreads();
   }
-  if (qv) {
+  merge_sum<SPLIT, 2>(comb, grp, wave, lane, acc);
+  if (qv && grp == 0) {
     float *qp = gqkv + ((((int64_t)b * T + q) * 3 + 0) * nh + hd) * HD;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       int r = acc_row(4 * g4, h);
-      *(float4 *)(qp + r) = make_float4(dq0[4 * g4], dq0[4 * g4 + 1], dq0[4 * g4 + 2], dq0[4 * g4 + 3]);
-      *(float4 *)(qp + 32 + r) = make_float4(dq1[4 * g4], dq1[4 * g4 + 1], dq1[4 * g4 + 2], dq1[4 * g4 + 3]);
+      *(float4 *)(qp + r) = make_float4(acc[0][4 * g4], acc[0][4 * g4 + 1], acc[0][4 * g4 + 2], acc[0][4 * g4 + 3]);
+      *(float4 *)(qp + 32 + r) = make_float4(acc[1][4 * g4], acc[1][4 * g4 + 1], acc[1][4 * g4 + 2], acc[1][4 * g4 + 3]);
     }
   }
 }
@@ -360,7 +442,7 @@ extern "C" int ftx_attn_fwd(const float *qkv, int32_t b, int32_t t, int32_t h, i
   if (rc != FTX_OK) return rc;
   FTX_REQUIRE(qkv && out && lse, "ftx_attn_fwd: null pointer");
   dim3 grid((unsigned)ceil_div(t, 128), (unsigned)h, (unsigned)b);
-  attn_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(qkv, t, h, scale, out, lse);
+  attn_fwd_kernel<ATT_SPLIT><<<grid, 256 * ATT_SPLIT, 0, (hipStream_t)stream>>>(qkv, t, h, scale, out, lse);
   return check_launch("ftx_attn_fwd");
 }
 
@@ -383,7 +465,7 @@ extern "C" int ftx_attn_bwd(const float *qkv, const float *out, const float *gra
   const int64_t rows = (int64_t)b * t * h;
   attn_delta_kernel<<<(unsigned)ceil_div(rows * 16, 256), 256, 0, st>>>(out, grad_out, rows, t, h, delta);
   dim3 grid((unsigned)ceil_div(t, 128), (unsigned)h, (unsigned)b);
-  attn_bwd_kv_kernel<<<grid, 256, 0, st>>>(qkv, grad_out, lse, delta, t, h, scale, grad_qkv);
-  attn_bwd_q_kernel<<<grid, 256, 0, st>>>(qkv, grad_out, lse, delta, t, h, scale, grad_qkv);
+  attn_bwd_kv_kernel<ATT_SPLIT><<<grid, 256 * ATT_SPLIT, 0, st>>>(qkv, grad_out, lse, delta, t, h, scale, grad_qkv);
+  attn_bwd_q_kernel<ATT_SPLIT><<<grid, 256 * ATT_SPLIT, 0, st>>>(qkv, grad_out, lse, delta, t, h, scale, grad_qkv);
   return check_launch("ftx_attn_bwd");
 }
