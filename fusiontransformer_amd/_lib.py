@@ -44,6 +44,8 @@ SIGNATURES = {
     "ftx_segment_build": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "ftx_voxelize_fwd_sorted": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),
     "ftx_devoxelize_bwd_sorted": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),
+    "ftx_segment_sum": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),
+    "ftx_lift_cells": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ftx_lift_gather_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ftx_lift_gather_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ftx_resample_nearest_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),

@@ -229,7 +229,8 @@ extern "C" int ftx_segment_build(const int32_t *keys, int64_t n, int64_t m, int3
 // out[v,:] = sum over the entries e of segment v of  scale(e) * src[row(e),:]
 //   voxelize fwd:    row(e) = e,      scale = 1 / (segment length)
 //   devoxelize bwd:  row(e) = e >> 3, scale = w[e]
-template <bool DEVOX>
+// MODE 0: mean of src[e] (voxelize fwd); 1: sum of w[e] * src[e >> 3] (devoxelize bwd); 2: plain sum of src[e]
+template <int MODE>
 __global__ void segment_reduce_kernel(const float *__restrict__ src, const float *__restrict__ w, const int32_t *__restrict__ order,
                                       const int32_t *__restrict__ seg_off, int64_t m, int c, float *__restrict__ out) {
   const int cv = c >> 2;
@@ -238,7 +239,8 @@ __global__ void segment_reduce_kernel(const float *__restrict__ src, const float
     int64_t v = t / cv;
     int j = (int)(t - v * cv) * 4;
     const int lo = seg_off[v], hi = seg_off[v + 1];
-    const float inv = DEVOX ? 1.f : (float)(hi - lo);
+    constexpr bool DEVOX = MODE == 1;
+    const float inv = MODE == 0 ? (float)(hi - lo) : 1.f;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int e = lo;
     for (; e + 4 <= hi; e += 4) {   // four independent row loads in flight
@@ -279,7 +281,7 @@ extern "C" int ftx_voxelize_fwd_sorted(const float *feats, const int32_t *order,
   FTX_REQUIRE(n >= 0 && m >= 0 && c >= 4 && c % 4 == 0, "ftx_voxelize_fwd_sorted: bad size (c must be a multiple of 4)");
   if (m == 0) return FTX_OK;
   FTX_REQUIRE(seg_off && out && ((feats && order) || n == 0), "ftx_voxelize_fwd_sorted: null pointer");
-  segment_reduce_kernel<false><<<grid_for(m * (c / 4), 256), 256, 0, (hipStream_t)stream>>>(feats, nullptr, order, seg_off, m, c, out);
+  segment_reduce_kernel<0><<<grid_for(m * (c / 4), 256), 256, 0, (hipStream_t)stream>>>(feats, nullptr, order, seg_off, m, c, out);
   return check_launch("ftx_voxelize_fwd_sorted");
 }
 
@@ -288,8 +290,18 @@ extern "C" int ftx_devoxelize_bwd_sorted(const float *grad_out, const float *wei
   FTX_REQUIRE(n >= 0 && m >= 0 && c >= 4 && c % 4 == 0, "ftx_devoxelize_bwd_sorted: bad size (c must be a multiple of 4)");
   if (m == 0) return FTX_OK;
   FTX_REQUIRE(seg_off && grad_feats && ((grad_out && weights && order) || n == 0), "ftx_devoxelize_bwd_sorted: null pointer");
-  segment_reduce_kernel<true><<<grid_for(m * (c / 4), 256), 256, 0, (hipStream_t)stream>>>(grad_out, weights, order, seg_off, m, c, grad_feats);
+  segment_reduce_kernel<1><<<grid_for(m * (c / 4), 256), 256, 0, (hipStream_t)stream>>>(grad_out, weights, order, seg_off, m, c, grad_feats);
   return check_launch("ftx_devoxelize_bwd_sorted");
+}
+
+// out[v,:] = sum of src[e,:] over the entries e of segment v (fixed order): the generic atomic-free scatter-add.
+extern "C" int ftx_segment_sum(const float *src, const int32_t *order, const int32_t *seg_off, int64_t n, int32_t c, int64_t m, float *out,
+                               void *stream) {
+  FTX_REQUIRE(n >= 0 && m >= 0 && c >= 4 && c % 4 == 0, "ftx_segment_sum: bad size (c must be a multiple of 4)");
+  if (m == 0) return FTX_OK;
+  FTX_REQUIRE(seg_off && out && ((src && order) || n == 0), "ftx_segment_sum: null pointer");
+  segment_reduce_kernel<2><<<grid_for(m * (c / 4), 256), 256, 0, (hipStream_t)stream>>>(src, nullptr, order, seg_off, m, c, out);
+  return check_launch("ftx_segment_sum");
 }
 
 // ---------------------------------------------------------------- lift gather
@@ -335,6 +347,16 @@ __global__ void lift_gather_bwd_kernel(const float *__restrict__ go, const int64
   }
 }
 
+__global__ void lift_cells_kernel(const int64_t *__restrict__ img_idx, const int32_t *__restrict__ pb, int64_t n, int b, int gh, int gw,
+                                  int H, int W, int32_t *__restrict__ cells) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int sr = nearest_src((int)img_idx[i * 2 + 0], gh, H);
+    int sc = nearest_src((int)img_idx[i * 2 + 1], gw, W);
+    int fb = pb[i];
+    cells[i] = (fb >= 0 && fb < b && sr >= 0 && sc >= 0) ? (fb * gh + sr) * gw + sc : -1;
+  }
+}
+
 static int lift_check(const char *who, int64_t n, int b, int gh, int gw, int c, int H, int W) {
   FTX_REQUIRE(n >= 0 && b >= 1 && gh >= 1 && gw >= 1 && H >= 1 && W >= 1, "%s: bad size", who);
   FTX_REQUIRE(c >= 4 && c % 4 == 0, "%s: c must be a multiple of 4", who);
@@ -362,6 +384,17 @@ extern "C" int ftx_lift_gather_bwd(const float *grad_out, const int64_t *img_idx
   FTX_REQUIRE(grad_out && img_idx && point_batch, "ftx_lift_gather_bwd: null pointer");
   lift_gather_bwd_kernel<<<grid_for(n * (c / 4), 256), 256, 0, st>>>(grad_out, img_idx, point_batch, n, gh, gw, c, H, W, grad_grid);
   return check_launch("ftx_lift_gather_bwd");
+}
+
+// cells[i] = flat (frame, source row, source col) cell of point i in the (b, gh, gw) grid: the destination of the
+// lift gather's backward, so that it can run as ftx_segment_build + ftx_segment_sum instead of float atomics.
+extern "C" int ftx_lift_cells(const int64_t *img_idx, const int32_t *point_batch, int64_t n, int32_t b, int32_t gh, int32_t gw, int32_t H,
+                              int32_t W, int32_t *cells, void *stream) {
+  FTX_REQUIRE(n >= 0 && b >= 1 && gh >= 1 && gw >= 1 && H >= 1 && W >= 1, "ftx_lift_cells: bad size");
+  if (n == 0) return FTX_OK;
+  FTX_REQUIRE(img_idx && point_batch && cells, "ftx_lift_cells: null pointer");
+  lift_cells_kernel<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(img_idx, point_batch, n, b, gh, gw, H, W, cells);
+  return check_launch("ftx_lift_cells");
 }
 
 // ---------------------------------------------------------------- NCHW nearest resample

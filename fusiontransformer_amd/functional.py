@@ -548,9 +548,20 @@ def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1
 
 
 # ---------------------------------------------------------------- 2D -> 3D lift, nearest resample
+def lift_segments(img_idx, point_batch, b, gh, gw, H, W) -> Segments:
+    """Points sorted by the grid cell they read: turns the lift's backward into a gather-reduce."""
+    L = _lib.load()
+    req(img_idx, I64, "lift img_idx", 2)
+    req(point_batch, I32, "lift point_batch", 1)
+    n = img_idx.shape[0]
+    cells = _empty((n,), I32, point_batch)
+    check(L.ftx_lift_cells(ptr(img_idx), ptr(point_batch), n, int(b), int(gh), int(gw), int(H), int(W), ptr(cells), stream()), "ftx_lift_cells")
+    return Segments(cells, int(b) * int(gh) * int(gw))
+
+
 class _LiftGather(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, grid, img_idx, point_batch, H, W):
+    def forward(ctx, grid, img_idx, point_batch, H, W, seg):
         L = _lib.load()
         grid = req(grid.contiguous(), F32, "lift grid", 4)
         req(img_idx, I64, "lift img_idx", 2)
@@ -563,6 +574,7 @@ class _LiftGather(torch.autograd.Function):
         check(L.ftx_lift_gather_fwd(ptr(grid), ptr(img_idx), ptr(point_batch), n, b, gh, gw, c, int(H), int(W), ptr(out), stream()), "ftx_lift_gather_fwd")
         ctx.save_for_backward(img_idx, point_batch)
         ctx.dims = (b, gh, gw, c, int(H), int(W))
+        ctx.seg = seg
         return out
 
     @staticmethod
@@ -572,13 +584,20 @@ class _LiftGather(torch.autograd.Function):
         b, gh, gw, c, H, W = ctx.dims
         go = req(go.contiguous(), F32, "lift grad", 2)
         gg = _empty((b, gh, gw, c), F32, go)
-        check(L.ftx_lift_gather_bwd(ptr(go), ptr(img_idx), ptr(point_batch), go.shape[0], b, gh, gw, c, H, W, ptr(gg), stream()), "ftx_lift_gather_bwd")
-        return gg, None, None, None, None
+        seg = ctx.seg
+        if seg is not None:
+            if seg.m != b * gh * gw or seg.order.shape[0] != go.shape[0]:
+                raise ValueError("lift_gather: segments do not match the grid / points")
+            check(L.ftx_segment_sum(ptr(go), ptr(seg.order), ptr(seg.seg_off), go.shape[0], c, seg.m, ptr(gg), stream()), "ftx_segment_sum")
+        else:
+            check(L.ftx_lift_gather_bwd(ptr(go), ptr(img_idx), ptr(point_batch), go.shape[0], b, gh, gw, c, H, W, ptr(gg), stream()), "ftx_lift_gather_bwd")
+        return gg, None, None, None, None, None
 
 
-def lift_gather(grid, img_idx, point_batch, H, W):
-    """Per-point rows of nearest-upsample(grid -> (H,W)) without materialising the map."""
-    return _LiftGather.apply(grid, img_idx, point_batch, H, W)
+def lift_gather(grid, img_idx, point_batch, H, W, seg=None):
+    """Per-point rows of nearest-upsample(grid -> (H,W)) without materialising the map.
+    `seg` = lift_segments(...) makes the backward an atomic-free, bit-reproducible gather-reduce."""
+    return _LiftGather.apply(grid, img_idx, point_batch, H, W, seg)
 
 
 class _ResampleNearest(torch.autograd.Function):

@@ -143,7 +143,15 @@ class Net2DBillinear(nn.Module):
         g = 384 // 16
         grid = self.up[block_id].forward_tokens(x, (g, g))
         idx, frame = pack_img_indices(img_indices, x.device)
-        return spf.lift_gather(grid, idx, frame, self.lift_size[0], self.lift_size[1])
+        seg = None
+        if torch.is_grad_enabled() and grid.requires_grad:
+            key = (idx.data_ptr(), frame.data_ptr(), grid.shape[0], g, self.lift_size)
+            cache = getattr(self, "_lift_seg", None)
+            if cache is None or cache[0] != key:       # both taps of a forward share one sort
+                cache = (key, spf.lift_segments(idx, frame, grid.shape[0], g, g, self.lift_size[0], self.lift_size[1]))
+                object.__setattr__(self, "_lift_seg", cache)
+            seg = cache[1]
+        return spf.lift_gather(grid, idx, frame, self.lift_size[0], self.lift_size[1], seg)
 
     def forward(self, img, img_indices, on_middle=None):
         """reference image_models_billinear.py:128-155.  `on_middle(feats)` is called with the lifted

@@ -121,6 +121,9 @@ int ftx_voxelize_fwd_sorted(const float *feats, const int32_t *order, const int3
 /* grad_feats[v] = sum over entries e=(p,k) of voxel v of weights[e] * grad_out[p]; weights (n,8) flattened, n = points. */
 int ftx_devoxelize_bwd_sorted(const float *grad_out, const float *weights, const int32_t *order, const int32_t *seg_off, int64_t n, int32_t c, int64_t m, float *grad_feats, void *stream);
 
+/* out[v] = sum of src[e] over the entries of segment v, in entry order (generic atomic-free scatter-add); out (m,c) fully written. */
+int ftx_segment_sum(const float *src, const int32_t *order, const int32_t *seg_off, int64_t n, int32_t c, int64_t m, float *out, void *stream);
+
 /* ---- 2D -> 3D lift ------------------------------------------------------- */
 
 /* Fused `nn.Upsample((H,W))` (nearest) + per-point gather of
@@ -131,6 +134,10 @@ int ftx_devoxelize_bwd_sorted(const float *grad_out, const float *weights, const
 int ftx_lift_gather_fwd(const float *grid, const int64_t *img_idx, const int32_t *point_batch, int64_t n, int32_t b, int32_t gh, int32_t gw, int32_t c, int32_t H, int32_t W, float *out, void *stream);
 /* bwd: grad_grid (b,gh,gw,c) zeroed here, scatter-add of grad_out rows. */
 int ftx_lift_gather_bwd(const float *grad_out, const int64_t *img_idx, const int32_t *point_batch, int64_t n, int32_t b, int32_t gh, int32_t gw, int32_t c, int32_t H, int32_t W, float *grad_grid, void *stream);
+
+/* cells[i] = flat index (frame, source row, source col) of point i's cell in the (b, gh, gw) grid (-1 if out of range):
+ * keys for ftx_segment_build so that the lift backward is ftx_segment_sum over the grid cells (no float atomics). */
+int ftx_lift_cells(const int64_t *img_idx, const int32_t *point_batch, int64_t n, int32_t b, int32_t gh, int32_t gw, int32_t H, int32_t W, int32_t *cells, void *stream);
 
 /* `nn.Upsample((oh,ow))` nearest on NCHW: models/image_models_billinear.py:17,41.
  * in (b,c,ih,iw) -> out (b,c,oh,ow). bwd zeroes grad_in and scatter-adds. */

@@ -304,6 +304,15 @@ def test_lift_gather_and_resample_match_golden_rule(env):
     g = rng.standard_normal(ref.shape).astype(np.float32)
     ref.backward(torch.from_numpy(g)); out.backward(dev(g))
     np.testing.assert_allclose(gg.grad.cpu().numpy(), go_t.grad.permute(0, 2, 3, 1).numpy(), rtol=1e-4, atol=1e-4)
+    # sorted-segment backward: same values, bit-identical from run to run
+    seg = spf.lift_segments(pi, pb, B, gh, gw, H, W)
+    grads = []
+    for _ in range(2):
+        g2 = dev(grid).requires_grad_(True)
+        spf.lift_gather(g2, pi, pb, H, W, seg).backward(dev(g))
+        grads.append(g2.grad)
+    np.testing.assert_allclose(grads[0].cpu().numpy(), go_t.grad.permute(0, 2, 3, 1).numpy(), rtol=1e-4, atol=1e-4)
+    assert torch.equal(grads[0], grads[1])
     # NCHW nearest resample 370x1226 -> 384x384 (sample_down)
     img = rng.standard_normal((2, 3, 370, 1226)).astype(np.float32)
     it = torch.from_numpy(img).requires_grad_(True)
@@ -389,3 +398,81 @@ def test_bad_arguments_fail_loudly(env):
         z = torch.zeros((8,), dtype=torch.int32, device="cuda")
         spf._spconv_apply(x, torch.zeros((27, 6, 8), device="cuda"), z, torch.zeros((27, 8), dtype=torch.int32, device="cuda"),
                           torch.zeros((28,), dtype=torch.int32, device="cuda"), 8, 8, 8, 0)
+
+
+# ---------------------------------------------------------------- edge cases
+def test_duplicate_points_and_counts_at_stride_one(env):
+    """Input that was NOT deduped: several points per stride-1 voxel (counts > 1), as initial_voxelize allows."""
+    spf, O = env
+    from fusiontransformer_amd.models.utils import initial_voxelize, point_to_voxel, voxel_to_point
+    from fusiontransformer_amd.sparse import PointTensor
+    rng = np.random.default_rng(20)
+    base = random_coords(rng, 500, extent=20, batch=2).astype(np.float32)
+    coords = np.concatenate([base, base[:200], base[:50]], 0)          # duplicates
+    feats = rng.standard_normal((coords.shape[0], 4)).astype(np.float32)
+    zo = O.PointTensor(torch.from_numpy(feats), coords.copy())
+    xo = O.initial_voxelize(zo, 1, 1)
+    zg = PointTensor(dev(feats), dev(coords))
+    xg = initial_voxelize(zg, 1, 1)
+    assert np.array_equal(xg.C.cpu().numpy(), xo.C)
+    assert np.array_equal(zg.additional_features["counts"][1].cpu().numpy(), zo.additional_features["counts"][1])
+    assert zg.additional_features["counts"][1].max().item() == 3
+    np.testing.assert_allclose(xg.F.cpu().numpy(), xo.F.numpy(), rtol=1e-5, atol=1e-6)
+    # round trip through voxel_to_point / point_to_voxel at stride 1 (weights are exactly 1 on corner 0)
+    po, pg = O.voxel_to_point(xo, zo), voxel_to_point(xg, zg)
+    np.testing.assert_allclose(pg.F.cpu().numpy(), po.F.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(point_to_voxel(xg, pg).F.cpu().numpy(), O.point_to_voxel(xo, po).F.numpy(), rtol=1e-5, atol=1e-6)
+    # nearest=True keeps corner 0 only
+    zg2 = PointTensor(dev(feats), dev(coords)); xg2 = initial_voxelize(zg2, 1, 1)
+    zo2 = O.PointTensor(torch.from_numpy(feats), coords.copy()); xo2 = O.initial_voxelize(zo2, 1, 1)
+    np.testing.assert_allclose(voxel_to_point(xg2, zg2, nearest=True).F.cpu().numpy(), O.voxel_to_point(xo2, zo2, nearest=True).F.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_empty_and_tiny_inputs(env):
+    spf, O = env
+    z32 = lambda *s: torch.zeros(s, dtype=torch.int32, device="cuda")
+    # empty key sets
+    t = spf.HashTable(torch.zeros((0,), dtype=torch.int64, device="cuda"))
+    assert t.query(torch.tensor([5, 7], dtype=torch.int64, device="cuda")).tolist() == [-1, -1]
+    u, f, c = spf.unique_sorted(torch.zeros((0,), dtype=torch.int64, device="cuda"))
+    assert int(c.item()) == 0
+    assert spf.spcount(z32(0), 3).tolist() == [0, 0, 0]
+    # a single voxel: every conv reduces to its centre weight
+    from fusiontransformer_amd.sparse import CoordinateManager
+    cm = CoordinateManager(); cm.coords[1] = torch.tensor([[3, 4, 5, 0]], dtype=torch.int32, device="cuda")
+    km = cm.kernel_map(3, 1, 1)
+    assert km.n_pairs == 1 and km.pair_in.tolist() == [0] and int(km.koff[13].item()) == 0 and int(km.koff[14].item()) == 1
+    x = torch.randn(1, 32, device="cuda", requires_grad=True)
+    w = torch.randn(27, 32, 64, device="cuda", requires_grad=True)
+    y = spf.sparse_conv(x, w, km, False)
+    torch.testing.assert_close(y, x @ w[13], rtol=1e-5, atol=1e-5)
+    y.sum().backward()
+    assert torch.count_nonzero(w.grad[:13]) == 0 and torch.count_nonzero(w.grad[14:]) == 0
+    # voxelize with rows that have no points: zero rows, no NaN
+    feats = torch.randn(5, 8, device="cuda")
+    idx = torch.tensor([0, 0, 2, -1, 2], dtype=torch.int32, device="cuda")
+    counts = spf.spcount(idx, 4)
+    for seg in (None, spf.voxelize_segments(idx, 4)):
+        out = spf.spvoxelize(feats, idx, counts, seg)
+        assert torch.isfinite(out).all() and torch.count_nonzero(out[1]) == 0 and torch.count_nonzero(out[3]) == 0
+        torch.testing.assert_close(out[0], feats[:2].mean(0), rtol=1e-5, atol=1e-6)
+
+
+def test_batch_with_an_empty_frame_and_far_coordinates(env):
+    """Frame index 1 has no points (ragged batch); coordinates sit at the edge of the 4096 range."""
+    spf, O = env
+    from fusiontransformer_amd.sparse import CoordinateManager
+    rng = np.random.default_rng(21)
+    c = random_coords(rng, 800, extent=30, batch=1)
+    c[:, 3] = np.where(rng.random(800) < 0.5, 0, 2)      # frames 0 and 2 only
+    c[:, :3] += 4060                                      # up to 4095
+    c = c[np.argsort(O.sphash(c))]
+    cm = CoordinateManager(); cm.coords[1] = dev(c)
+    for ks, cur, s in [(3, 1, 1), (2, 1, 2), (3, 2, 1), (2, 2, 2), (3, 4, 1)]:
+        km = cm.kernel_map(ks, cur, s)
+        ref_idx, ref_out = O.build_kernel_map(cm.coords[cur].cpu().numpy(), cur, ks, s)
+        assert np.array_equal(km.out_coords.cpu().numpy(), ref_out) and np.array_equal(km.nbr.cpu().numpy(), ref_idx)
+        # no neighbour ever crosses a frame boundary
+        nbr = km.nbr.cpu().numpy(); ci = cm.coords[cur].cpu().numpy(); co = ref_out
+        kk, oo = np.nonzero(nbr >= 0)
+        assert np.array_equal(ci[nbr[kk, oo], 3], co[oo, 3])
