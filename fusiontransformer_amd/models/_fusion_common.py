@@ -82,28 +82,63 @@ def bump_batchnorm_counters(model):
         torch._foreach_add_(live, 1)
 
 
-def run_fusion(model, data_dict, lidar_call, overlap=True):
+def _drain(steps):
+    while True:
+        try:
+            next(steps)
+        except StopIteration as done:
+            return done.value
+
+
+def run_fusion(model, data_dict, lidar_steps, overlap=True):
     """Runs the image branch and the LiDAR branch of a fusion model.
 
-    On the GPU the two branches are issued on two HIP streams: the ViT is a chain of large dense
-    GEMMs, the SPVCNN a long chain of small gather / scatter kernels and host-synchronising index
-    builds; they share nothing until the fusion add, so they overlap (forward and, through
-    autograd's stream tracking, backward).  `lidar_call(lazy_feats)` runs the LiDAR branch."""
+    `lidar_steps(lazy_feats)` returns a generator that issues the LiDAR branch stage by stage and
+    returns its prediction dict.  On the GPU the two branches go to two HIP streams and their kernel
+    launches are INTERLEAVED: after every ViT block the scheduler issues one LiDAR stage.  The ViT is a
+    chain of large dense GEMMs, the SPVCNN a long chain of small gather / scatter kernels and
+    host-synchronising index builds; they share nothing until the fusion add (one event), so they
+    overlap -- in the forward and, because autograd replays nodes in reverse creation order on their
+    forward streams, in the backward as well.  Interleaving the issue matters: issuing one branch
+    completely before the other leaves the second stream empty for that long."""
     img = data_dict["img"]
     lazy = _Lazy()
     if model.training:
         bump_batchnorm_counters(model)
     if not (overlap and img.is_cuda):
         preds_image = model.image_backbone(img=img, img_indices=data_dict["img_indices"], on_middle=lazy.set)
-        return lidar_call(lazy), preds_image
+        return _drain(lidar_steps(lazy)), preds_image
     cur = torch.cuda.current_stream()
     s_img, s_lid = _branch_streams(img.device)
     s_img.wait_stream(cur)
     s_lid.wait_stream(cur)
+    gen = lidar_steps(lazy)
+    state = {"done": False, "blocked": False, "preds": None}
+
+    def pump():
+        """Issue one more LiDAR stage (unless it waits for image features that do not exist yet)."""
+        if state["done"]:
+            return
+        if state["blocked"]:
+            if lazy.feats is None:
+                return
+            state["blocked"] = False
+        with torch.cuda.stream(s_lid):
+            try:
+                token = next(gen)
+            except StopIteration as done:
+                state["preds"], state["done"] = done.value, True
+                return
+        if isinstance(token, str) and token.startswith("need_") and lazy.feats is None:
+            state["blocked"] = True
+
     with torch.cuda.stream(s_img):
-        preds_image = model.image_backbone(img=img, img_indices=data_dict["img_indices"], on_middle=lazy.set)
-    with torch.cuda.stream(s_lid):
-        preds_lidar = lidar_call(lazy)
+        preds_image = model.image_backbone(img=img, img_indices=data_dict["img_indices"], on_middle=lazy.set, on_step=pump)
+    while not state["done"]:
+        if state["blocked"] and lazy.feats is None:
+            raise RuntimeError("the LiDAR branch needs image features the image branch never produced")
+        pump()
+    preds_lidar = state["preds"]
     cur.wait_stream(s_img)
     cur.wait_stream(s_lid)
     for d in (preds_image, preds_lidar):

@@ -13,15 +13,22 @@ class Net3DSeg(SPVCNN):
         self.early_fusion_transform = nn.Sequential(nn.Linear(96, 32), BatchNorm(32), nn.ReLU(True))
         heads(self, self.cs[-1], num_classes, dual_head)
 
-    def backbone_forward_pass(self, x, img_early_feats):
+    def _fuse(self, img_early_feats):
         # z0.F = z0.F + early_fusion_transform(img_early_feats)  (early_fusion.py:39)
         def fuse():
             feats = img_early_feats.get() if hasattr(img_early_feats, "get") else img_early_feats
             return _linear_bn_relu(self.early_fusion_transform, feats)
-        return self._backbone(x, fuse_early=fuse)
+        return fuse
+
+    def backbone_forward_pass(self, x, img_early_feats):
+        return self._backbone(x, fuse_early=self._fuse(img_early_feats))
 
     def forward(self, x, img_early_feats):
         return lidar_preds(self, self.backbone_forward_pass(x, img_early_feats))
+
+    def forward_steps(self, x, img_early_feats):
+        feats = yield from self._backbone_steps(x, fuse_early=self._fuse(img_early_feats))
+        return lidar_preds(self, feats)
 
 
 class EarlyFusionTransformer(nn.Module):
@@ -33,6 +40,6 @@ class EarlyFusionTransformer(nn.Module):
 
     def forward(self, data_dict):
         # with middle_feat_block_number = 0 the "middle" tap is the early one (early_fusion.py:101-105)
-        preds_lidar, preds_image = run_fusion(self, data_dict, lambda feats: self.lidar_backbone(x=data_dict["lidar"], img_early_feats=feats),
+        preds_lidar, preds_image = run_fusion(self, data_dict, lambda feats: self.lidar_backbone.forward_steps(data_dict["lidar"], feats),
                                               overlap=getattr(self, "overlap_branches", True))
         return fused_outputs(self.dual_head, preds_lidar, preds_image)

@@ -153,12 +153,15 @@ class Net2DBillinear(nn.Module):
             seg = cache[1]
         return spf.lift_gather(grid, idx, frame, self.lift_size[0], self.lift_size[1], seg)
 
-    def forward(self, img, img_indices, on_middle=None):
+    def forward(self, img, img_indices, on_middle=None, on_step=None):
         """reference image_models_billinear.py:128-155.  `on_middle(feats)` is called with the lifted
         features of the middle tap as soon as that block has run (the LiDAR branch, on another
-        stream, only waits for this and not for the rest of the ViT)."""
+        stream, only waits for this and not for the rest of the ViT); `on_step()` after every issued
+        chunk of work (the scheduler uses it to interleave the other branch's kernel launches)."""
         img_indices = pack_img_indices(img_indices, img.device)
         x = self.sample_down(img)
+        if on_step is not None:
+            on_step()
         middle = {}
 
         def tap(i, tokens):
@@ -166,6 +169,8 @@ class Net2DBillinear(nn.Module):
                 middle["feats"] = self.get_img_feats(img_indices, self.middle_feat_block_number, img.shape, {self.middle_feat_block_number: tokens})
                 if on_middle is not None:
                     on_middle(middle["feats"])
+            if on_step is not None:
+                on_step()
 
         backbone_output = self.backbone.forward_blocks(x, on_block=tap)
         late_feats = self.get_img_feats(img_indices, self.late_feat_block_number, img.shape, backbone_output)

@@ -16,6 +16,10 @@ class Net3DSeg(nn.Module):
     def forward(self, x):
         return lidar_preds(self, self.backbone(x))
 
+    def forward_steps(self, x):
+        feats = yield from self.backbone._backbone_steps(x)
+        return lidar_preds(self, feats)
+
 
 class LateFusionTransformer(nn.Module):
     def __init__(self, num_class, dual_head, backbone_3d_kwargs, backbone_2d_kwargs):
@@ -25,6 +29,6 @@ class LateFusionTransformer(nn.Module):
         self.image_backbone = image_branch(num_class, dual_head, backbone_2d_kwargs)
 
     def forward(self, data_dict):
-        preds_lidar, preds_image = run_fusion(self, data_dict, lambda feats: self.lidar_backbone(data_dict["lidar"]),
+        preds_lidar, preds_image = run_fusion(self, data_dict, lambda feats: self.lidar_backbone.forward_steps(data_dict["lidar"]),
                                               overlap=getattr(self, "overlap_branches", True))
         return fused_outputs(self.dual_head, preds_lidar, preds_image)

@@ -13,16 +13,23 @@ class Net3DSeg(SPVCNN):
         self.middle_fusion_transform = nn.Sequential(nn.Linear(96, self.cs[4]), BatchNorm(self.cs[4]), nn.ReLU(True))
         heads(self, self.cs[-1], num_classes, dual_head)
 
-    def backbone_forward_pass(self, x, img_middle_feats):
+    def _fuse(self, img_middle_feats):
         # z1.F = z1.F + point_transforms[0](z0.F) + middle_fusion_transform(img_middle_feats)  (middle_fusion.py:48)
         # img_middle_feats may be a lazy hand-off from the image stream: it is only touched at the fusion point
         def fuse():
             feats = img_middle_feats.get() if hasattr(img_middle_feats, "get") else img_middle_feats
             return _linear_bn_relu(self.middle_fusion_transform, feats)
-        return self._backbone(x, fuse_middle=fuse)
+        return fuse
+
+    def backbone_forward_pass(self, x, img_middle_feats):
+        return self._backbone(x, fuse_middle=self._fuse(img_middle_feats))
 
     def forward(self, x, img_middle_feats):
         return lidar_preds(self, self.backbone_forward_pass(x, img_middle_feats))
+
+    def forward_steps(self, x, img_middle_feats):
+        feats = yield from self._backbone_steps(x, fuse_middle=self._fuse(img_middle_feats))
+        return lidar_preds(self, feats)
 
 
 class MiddleFusionTransformer(nn.Module):
@@ -33,6 +40,6 @@ class MiddleFusionTransformer(nn.Module):
         self.image_backbone = image_branch(num_class, dual_head, backbone_2d_kwargs)
 
     def forward(self, data_dict):
-        preds_lidar, preds_image = run_fusion(self, data_dict, lambda feats: self.lidar_backbone(x=data_dict["lidar"], img_middle_feats=feats),
+        preds_lidar, preds_image = run_fusion(self, data_dict, lambda feats: self.lidar_backbone.forward_steps(data_dict["lidar"], feats),
                                               overlap=getattr(self, "overlap_branches", True))
         return fused_outputs(self.dual_head, preds_lidar, preds_image)

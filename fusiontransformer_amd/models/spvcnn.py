@@ -199,48 +199,71 @@ class SPVCNN(nn.Module):
 
     def _backbone(self, x, fuse_early=None, fuse_middle=None):
         """spvcnn.py:191-233 with the fusion adds of early_fusion.py:39 / middle_fusion.py:48."""
+        steps = self._backbone_steps(x, fuse_early, fuse_middle)
+        while True:
+            try:
+                next(steps)
+            except StopIteration as done:
+                return done.value
+
+    def _backbone_steps(self, x, fuse_early=None, fuse_middle=None):
+        """The same forward as a generator that yields at stage boundaries, so a scheduler can interleave
+        the issue of this branch with the image branch (see _fusion_common.run_fusion).  It yields
+        "need_early" / "need_middle" right before it touches the image features."""
         coords = x.C
         if coords.dtype != torch.float32:
             coords = coords.float()
         z = PointTensor(x.F, coords.contiguous())
 
         x0 = initial_voxelize(z, self.pres, self.vres)
+        yield "voxelized"
         x0 = self._stem(x0)
         z0 = voxel_to_point(x0, z, nearest=False)
         if fuse_early is not None:
+            yield "need_early"
             z0.F = z0.F + (fuse_early() if callable(fuse_early) else fuse_early)
+        yield "stem"
 
         x1 = point_to_voxel(x0, z0)
         x1 = self.stage1(x1)
+        yield "stage1"
         x2 = self.stage2(x1)
+        yield "stage2"
         x3 = self.stage3(x2)
+        yield "stage3"
         x4 = self.stage4(x3)
         z1 = voxel_to_point(x4, z0)
         z1.F = z1.F + _linear_bn_relu(self.point_transforms[0], z0.F)
         if fuse_middle is not None:
+            yield "need_middle"
             z1.F = z1.F + (fuse_middle() if callable(fuse_middle) else fuse_middle)
+        yield "stage4"
 
         y1 = point_to_voxel(x4, z1)
         y1.F = self._drop(y1.F, "y1")
         y1 = self.up1[0](y1)
         y1 = cat([y1, x3])
         y1 = self.up1[1](y1)
+        yield "up1"
 
         y2 = self.up2[0](y1)
         y2 = cat([y2, x2])
         y2 = self.up2[1](y2)
         z2 = voxel_to_point(y2, z1)
         z2.F = z2.F + _linear_bn_relu(self.point_transforms[1], z1.F)
+        yield "up2"
 
         y3 = point_to_voxel(y2, z2)
         y3.F = self._drop(y3.F, "y3")
         y3 = self.up3[0](y3)
         y3 = cat([y3, x1])
         y3 = self.up3[1](y3)
+        yield "up3"
 
         y4 = self.up4[0](y3)
         y4 = cat([y4, x0])
         y4 = self.up4[1](y4)
+        yield "up4"
         z3 = voxel_to_point(y4, z2)
         z3.F = z3.F + _linear_bn_relu(self.point_transforms[2], z2.F)
         self.last_index = dict(x0=x0, x1=x1, x2=x2, x3=x3, x4=x4, z=z)
