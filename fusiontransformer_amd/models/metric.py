@@ -18,14 +18,14 @@ class SegIoU(object):
         seg_label = labels["seg_label"].detach().long().to(seg_logit.device)
         pred_label = seg_logit.detach().argmax(1)
         mask = seg_label != self.ignore_index
-        seg_label = seg_label[mask]
-        pred_label = pred_label[mask]
         n = self.num_classes
         with torch.no_grad():
             if self.mat is None:
                 self.mat = seg_label.new_zeros((n, n))
-            inds = n * seg_label + pred_label
-            self.mat += torch.bincount(inds, minlength=n ** 2).reshape(n, n)
+            # same counts as the reference's bincount over the masked points, without its two host
+            # synchronisations (boolean-mask indexing and bincount both need a size from the device)
+            inds = (n * seg_label + pred_label).clamp_(0, n * n - 1)
+            self.mat.view(-1).index_add_(0, inds, mask.to(self.mat.dtype))
 
     def reset(self):
         self.mat = None

@@ -51,6 +51,7 @@ class TrainStep:
         self.dual_head = bool(cfg.MODEL.DUAL_HEAD)
         self.metrics = metrics or ()
         self.grad_reducer = grad_reducer
+        self.fused_loss = True
         self.last = {}
 
     def __call__(self, data_batch):
@@ -59,10 +60,22 @@ class TrainStep:
         else:
             self.optimizer.zero_grad(set_to_none=True)    # first write of each gradient is a move, not fill + add
         preds = self.model(data_batch)
-        loss_2d, loss_3d = fusion_losses(preds, data_batch["seg_label"], self.class_weights, self.lambda_xm, self.dual_head)
-        with torch.no_grad():
+        logits = preds["lidar_seg_logit"]
+        if self.fused_loss and logits.is_cuda and logits.shape[1] % 4 == 0 and logits.shape[1] <= 32:
+            # one fused pass: CE x2 + KL x2 + their gradients + both SegIoU confusion matrices (libftx)
+            conf = {"3d": None, "2d": None}
             for m in self.metrics:
-                m.update_dict(preds, data_batch)
+                if m.mat is None:
+                    m.mat = torch.zeros((m.num_classes, m.num_classes), dtype=torch.int64, device=logits.device)
+                conf["3d" if "3d" in m.name else "2d"] = m.mat
+            from . import functional as spf
+            loss_2d, loss_3d = spf.fusion_loss(preds, data_batch["seg_label"], self.class_weights, self.lambda_xm, self.dual_head,
+                                               conf3d=conf["3d"], conf2d=conf["2d"])
+        else:
+            loss_2d, loss_3d = fusion_losses(preds, data_batch["seg_label"], self.class_weights, self.lambda_xm, self.dual_head)
+            with torch.no_grad():
+                for m in self.metrics:
+                    m.update_dict(preds, data_batch)
         (loss_2d + loss_3d).backward()
         if self.grad_reducer is not None:
             self.grad_reducer.finish()

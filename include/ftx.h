@@ -205,6 +205,16 @@ int ftx_attn_fwd(const float *qkv, int32_t b, int32_t t, int32_t h, int32_t d, f
 size_t ftx_attn_bwd_workspace_bytes(int32_t b, int32_t t, int32_t h);
 int ftx_attn_bwd(const float *qkv, const float *out, const float *grad_out, const float *lse, int32_t b, int32_t t, int32_t h, int32_t d, float scale, float *grad_qkv, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- fused train-step losses + metric: modules/SemanticTrainer.py:158-194, models/metric.py:37-58 ----
+ * losses[0] = loss_2d = CE_w(img_logit) + lambda * KL(softmax(lidar_logit) || softmax(img_logit2))
+ * losses[1] = loss_3d = CE_w(lidar_logit) + lambda * KL(softmax(img_logit) || softmax(lidar_logit2))
+ * (weighted-mean CE with class_weights (c) or NULL = ones; KL summed over classes, mean over points;
+ * second heads NULL = single head, the KL terms then use the main heads, SemanticTrainer.py:164-165).
+ * grad_* (n,c) receive d(loss_2d + loss_3d)/d(logits), fully written.  conf3d / conf2d (c,c) int64 are
+ * ACCUMULATED: conf[label, argmax] += 1 for label != ignore_index (NULL = no metric).  c % 4 == 0, c <= 32. */
+size_t ftx_fusion_loss_workspace_bytes(void);
+int ftx_fusion_loss(const float *lidar_logit, const float *img_logit, const float *lidar_logit2, const float *img_logit2, const int64_t *label, const float *class_weights, float lambda_xm, int64_t n, int32_t c, int32_t ignore_index, float *losses, float *grad_lidar, float *grad_img, float *grad_lidar2, float *grad_img2, int64_t *conf3d, int64_t *conf2d, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

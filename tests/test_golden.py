@@ -105,3 +105,40 @@ def test_product_lift_and_resample_match_reference_goldens():
     down = down.cuda().train()
     out = down(torch.from_numpy(g["img_q"].astype(np.float32) / 256.0).cuda()).detach().cpu().numpy()
     np.testing.assert_allclose(out, g["down_out"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_fused_loss_kernel_matches_reference_goldens():
+    """ftx_fusion_loss against the loss values / confusion matrices the reference code produced, and its
+    gradients against autograd through the reference's own statements."""
+    from fusiontransformer_amd import functional as spf
+    from fusiontransformer_amd.trainer import fusion_losses
+    g = load("losses_metric.npz")
+    names = ("lidar_seg_logit", "img_seg_logit", "lidar_seg_logit2", "img_seg_logit2")
+    label = torch.from_numpy(g["label"]).cuda()
+    cw = torch.from_numpy(g["class_weights"]).cuda()
+    lam = float(g["lambda_xm"])
+    for dual in (True, False):
+        preds = {k: torch.from_numpy(g[k]).cuda().requires_grad_(True) for k in names}
+        ref = {k: torch.from_numpy(g[k]).double().requires_grad_(True) for k in names}
+        c3 = torch.zeros((20, 20), dtype=torch.int64, device="cuda")
+        c2 = torch.zeros_like(c3)
+        l2, l3 = spf.fusion_loss(preds, label, cw, lam, dual, conf3d=c3, conf2d=c2)
+        r2, r3 = fusion_losses(ref, label.cpu(), cw.cpu().double(), lam, dual)
+        (l2 + l3).backward()
+        (r2 + r3).backward()
+        assert abs(l2.item() - r2.item()) < 2e-6 and abs(l3.item() - r3.item()) < 2e-6
+        if dual:
+            assert abs(l2.item() - float(g["loss_2d"])) < 2e-6 and abs(l3.item() - float(g["loss_3d"])) < 2e-6
+        assert np.array_equal(c3.cpu().numpy(), g["mat3d"]) and np.array_equal(c2.cpu().numpy(), g["mat2d"])
+        for k in names:
+            if ref[k].grad is None:
+                assert preds[k].grad is None
+                continue
+            np.testing.assert_allclose(preds[k].grad.cpu().numpy(), ref[k].grad.numpy(), rtol=1e-4, atol=1e-9)
+    # unweighted form and a second accumulation into the same matrices
+    preds = {k: torch.from_numpy(g[k]).cuda() for k in names}
+    l2, l3 = spf.fusion_loss(preds, label, None, 0.0, True, conf3d=c3, conf2d=c2)
+    r2, r3 = fusion_losses({k: v.cpu() for k, v in preds.items()}, label.cpu(), None, 0.0, True)
+    assert abs(l2.item() - r2.item()) < 2e-6 and abs(l3.item() - r3.item()) < 2e-6
+    assert np.array_equal(c3.cpu().numpy(), 2 * g["mat3d"])
