@@ -142,3 +142,18 @@ def test_fused_loss_kernel_matches_reference_goldens():
     r2, r3 = fusion_losses({k: v.cpu() for k, v in preds.items()}, label.cpu(), None, 0.0, True)
     assert abs(l2.item() - r2.item()) < 2e-6 and abs(l3.item() - r3.item()) < 2e-6
     assert np.array_equal(c3.cpu().numpy(), 2 * g["mat3d"])
+
+
+@pytest.mark.gpu
+def test_gpu_voxelisation_matches_reference_augment_and_scale():
+    from fusiontransformer_amd.data.voxelize import points_to_voxels
+    g = load("voxel_coords.npz")
+    pts = g["points"]
+    coords, keep = points_to_voxels(torch.from_numpy(pts).cuda())
+    # reference: augment_and_scale_3d -> int64 -> range mask (golden), then first point per voxel in sorted-key order
+    ci, valid = g["coords_int"], g["valid"]
+    rows = np.nonzero(valid)[0]
+    key = (ci[rows, 0] * 4096 + ci[rows, 1]) * 4096 + ci[rows, 2]
+    _, inds = np.unique(key, return_index=True)
+    assert np.array_equal(keep.cpu().numpy(), rows[inds])
+    assert np.array_equal(coords.cpu().numpy(), ci[rows[inds]])
