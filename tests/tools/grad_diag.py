@@ -2,7 +2,7 @@
 oracle run in float64.  Separates rounding chaos (ReLU gates, train-mode BN) from real bugs."""
 import json, os, sys, copy
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tests.helpers import oracle_inputs, product_inputs, small_cfg
 from fusiontransformer_amd.data.synth import make_batch
 from fusiontransformer_amd.models.build import build_model
