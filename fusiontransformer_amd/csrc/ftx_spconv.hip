@@ -138,13 +138,12 @@ __global__ __launch_bounds__(256) void pairs_gemm_kernel(const float *__restrict
   // gather == nullptr: dense mode, tmp[r,:] = A[r,:] @ W (+ bias) for r < n_dense (kvol = 1)
   constexpr int TILE = TILE_P * RT;
   constexpr int BN = 32 * NT;
-  constexpr int BS_STRIDE = BN + 4;
-  constexpr int B_VEC = BK * BN / 4;           // float4 per W chunk
-  constexpr int B_PASSES = (B_VEC + 255) / 256;
+  constexpr int BS_STRIDE = AS_STRIDE;         // W chunk kept as Bs[n][k]: the reduction index is contiguous for BOTH operands
+  constexpr int B_PASSES = NT;                 // BK * BN / 4 float4 per W chunk = NT * 256
   constexpr int A_PASSES = 4 * RT;
 
   __shared__ __attribute__((aligned(16))) float As[TILE * AS_STRIDE];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * BS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * BS_STRIDE];
   __shared__ int s_tile[3];
 
   const int tid = threadIdx.x;
@@ -218,16 +217,14 @@ __global__ __launch_bounds__(256) void pairs_gemm_kernel(const float *__restrict
     }
 #pragma unroll
     for (int q = 0; q < B_PASSES; ++q) {
-      int e = q * 256 + tid;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < B_VEC) {
-        if (!w_transposed) {
-          int kk = e / (BN / 4), n4 = (e - kk * (BN / 4)) * 4;
-          if (c0 + kk < ca && n0 + n4 < co) v = *(const float4 *)&Wk[(int64_t)(c0 + kk) * co + n0 + n4];
-        } else {  // W[k] stored (co, ca): 16 bytes along ca
-          int nn = e / (BK / 4), k4 = (e - nn * (BK / 4)) * 4;
-          if (n0 + nn < co && c0 + k4 < ca) v = *(const float4 *)&Wk[(int64_t)(n0 + nn) * ca + c0 + k4];
-        }
+      if (!w_transposed) {  // W[k] stored (ca, co): 16 bytes along co; a wave covers 8 k-rows x 128 B
+        int kk = ((tid >> 6) << 3) + (tid & 7), n4 = (q * 8 + ((tid >> 3) & 7)) * 4;
+        if (c0 + kk < ca && n0 + n4 < co) v = *(const float4 *)&Wk[(int64_t)(c0 + kk) * co + n0 + n4];
+      } else {              // W[k] stored (co, ca): 16 bytes along ca
+        int e = q * 256 + tid;
+        int nn = e >> 3, k4 = (e & 7) * 4;
+        if (n0 + nn < co && c0 + k4 < ca) v = *(const float4 *)&Wk[(int64_t)(n0 + nn) * ca + c0 + k4];
       }
       rb[q] = v;
     }
@@ -237,18 +234,16 @@ __global__ __launch_bounds__(256) void pairs_gemm_kernel(const float *__restrict
     for (int p = 0; p < A_PASSES; ++p) *(float4 *)&As[(p * 32 + arow) * AS_STRIDE + acol] = ra[p];
 #pragma unroll
     for (int q = 0; q < B_PASSES; ++q) {
-      int e = q * 256 + tid;
-      if (e < B_VEC) {
-        if (!w_transposed) {
-          int kk = e / (BN / 4), n4 = (e - kk * (BN / 4)) * 4;
-          *(float4 *)&Bs[kk * BS_STRIDE + n4] = rb[q];
-        } else {
-          int nn = e / (BK / 4), k4 = (e - nn * (BK / 4)) * 4;
-          Bs[(k4 + 0) * BS_STRIDE + nn] = rb[q].x;
-          Bs[(k4 + 1) * BS_STRIDE + nn] = rb[q].y;
-          Bs[(k4 + 2) * BS_STRIDE + nn] = rb[q].z;
-          Bs[(k4 + 3) * BS_STRIDE + nn] = rb[q].w;
-        }
+      if (!w_transposed) {  // transposing store; (n4i * 144 + kl) mod 64 banks: 2-way conflicts at worst
+        int kk = ((tid >> 6) << 3) + (tid & 7), n4 = (q * 8 + ((tid >> 3) & 7)) * 4;
+        Bs[(n4 + 0) * BS_STRIDE + kk] = rb[q].x;
+        Bs[(n4 + 1) * BS_STRIDE + kk] = rb[q].y;
+        Bs[(n4 + 2) * BS_STRIDE + kk] = rb[q].z;
+        Bs[(n4 + 3) * BS_STRIDE + kk] = rb[q].w;
+      } else {
+        int e = q * 256 + tid;
+        int nn = e >> 3, k4 = (e & 7) * 4;
+        *(float4 *)&Bs[nn * BS_STRIDE + k4] = rb[q];
       }
     }
   };
@@ -258,44 +253,62 @@ __global__ __launch_bounds__(256) void pairs_gemm_kernel(const float *__restrict
     store_chunk();
     __syncthreads();
     if (c0 + BK < ca) load_chunk(c0 + BK);  // next chunk's global loads fly under the MFMAs
+    // lane (l31, half) owns k = 8t + 4*half + s of both operands: one ds_read_b128 per operand row feeds 4 MFMAs.
+    // The fragments of step t+1 are in flight while the MFMAs of step t issue.
     const float *arow_p = &As[(wave * 32 * RT + l31) * AS_STRIDE + 4 * half];
-    const float *bcol_p = &Bs[(4 * half) * BS_STRIDE + l31];
-#pragma unroll
-    for (int t = 0; t < BK / 8; ++t) {
-      float av[RT][4];
+    const float *brow_p = &Bs[l31 * BS_STRIDE + 4 * half];
+    float af[2][RT][4], bf[2][NT][4];
+    auto load_frag = [&](int buf, int t) {
 #pragma unroll
       for (int r = 0; r < RT; ++r) {
         float4 a = *(const float4 *)(arow_p + r * 32 * AS_STRIDE + 8 * t);
-        av[r][0] = a.x; av[r][1] = a.y; av[r][2] = a.z; av[r][3] = a.w;
+        af[buf][r][0] = a.x; af[buf][r][1] = a.y; af[buf][r][2] = a.z; af[buf][r][3] = a.w;
       }
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          float b = bcol_p[(8 * t + s) * BS_STRIDE + j * 32];
-#pragma unroll
-          for (int r = 0; r < RT; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r][s], b, acc[r][j], 0, 0, 0);
-        }
+      for (int j = 0; j < NT; ++j) {
+        float4 b = *(const float4 *)(brow_p + j * 32 * BS_STRIDE + 8 * t);
+        bf[buf][j][0] = b.x; bf[buf][j][1] = b.y; bf[buf][j][2] = b.z; bf[buf][j][3] = b.w;
       }
+    };
+    load_frag(0, 0);
+#pragma unroll
+    for (int t = 0; t < BK / 8; ++t) {
+      if (t + 1 < BK / 8) load_frag((t + 1) & 1, t + 1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < RT; ++r)
+            acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[t & 1][j][s], af[t & 1][r][s], acc[r][j], 0, 0, 0);
     }
     __syncthreads();
   }
 
-  // ---- tmp rows of this tile are contiguous: each 32-lane half stores 128 bytes per register
+  // ---- W is the MFMA's row operand, so lane (pair l31, half) holds 4 consecutive output channels in every 4
+  // consecutive accumulator registers: 16-byte stores, each pair row receives 32 contiguous bytes per instruction
+  // (dword stores of the (pair, channel) orientation took 17k cycles per tile here, these take 6k)
 #pragma unroll
-  for (int r = 0; r < RT; ++r)
+  for (int r = 0; r < RT; ++r) {
+    const int row = wave * 32 * RT + r * 32 + l31;
+    if (row < cnt) {
+      float *dst = tmp + (int64_t)(p0 + row) * co;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      int col = n0 + j * 32 + l31;
-      if (col < co) {
-        const float bv = bias ? bias[col] : 0.f;
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          int row = wave * 32 * RT + r * 32 + (g & 3) + 8 * (g >> 2) + 4 * half;
-          if (row < cnt) tmp[(int64_t)(p0 + row) * co + col] = acc[r][j][g] + bv;
+        for (int q = 0; q < 4; ++q) {
+          const int col = n0 + j * 32 + 8 * q + 4 * half;
+          if (col < co) {
+            float4 v = make_float4(acc[r][j][4 * q], acc[r][j][4 * q + 1], acc[r][j][4 * q + 2], acc[r][j][4 * q + 3]);
+            if (bias) {
+              const float4 bv = *(const float4 *)&bias[col];
+              v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            }
+            *(float4 *)&dst[col] = v;
+          }
         }
-      }
     }
+  }
 }
 
 template <int RT>
@@ -534,7 +547,7 @@ __global__ __launch_bounds__(256) void pairs_wgrad_kernel(const float *__restric
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         float b = Gs[kk * GSTR + j * 32 + l31];
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc[j], 0, 0, 0);  // G rows: accumulator = (g-channel, a-channel)
       }
     }
   };
@@ -587,16 +600,16 @@ __global__ __launch_bounds__(256) void pairs_wgrad_kernel(const float *__restric
 
   if (ks == 0) {
     float *dst = part + (int64_t)blockIdx.x * ca * cg;   // one partial per tile, tiles are numbered in offset order
+    // lane (a-channel l31, half) holds 4 consecutive g-channels in every 4 consecutive registers: 16-byte stores
+    const int row = m0 + wm * 32 + l31;
+    if (row < ca) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      int col = n0 + j * 32 + l31;
-      if (col < cg) {
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          int row = m0 + wm * 32 + (g & 3) + 8 * (g >> 2) + 4 * half;
-          if (row < ca) dst[(int64_t)row * cg + col] = acc[j][g];
+        for (int q = 0; q < 4; ++q) {
+          const int col = n0 + j * 32 + 8 * q + 4 * half;
+          if (col < cg) *(float4 *)&dst[(int64_t)row * cg + col] = make_float4(acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
         }
-      }
     }
   }
 }
