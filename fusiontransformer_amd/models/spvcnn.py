@@ -9,6 +9,7 @@ launch plus one fused BN/residual/ReLU pass instead of four separate ops."""
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -16,7 +17,7 @@ import torch.nn.functional as F
 
 from .. import functional as spf
 from ..sparse import PointTensor, SparseTensor, cat
-from .utils import initial_voxelize, point_to_voxel, voxel_to_point
+from .utils import initial_voxelize, initial_voxelize_steps, point_to_voxel, voxel_to_point
 
 __all__ = ["SPVCNN", "Conv3d", "BatchNorm", "ReLU"]
 
@@ -215,7 +216,13 @@ class SPVCNN(nn.Module):
             coords = coords.float()
         z = PointTensor(x.F, coords.contiguous())
 
-        x0 = initial_voxelize(z, self.pres, self.vres)
+        # index structures first: they depend on the coordinates only.  Each data-dependent size is read back after
+        # a "sync" yield (6 per batch), so the scheduler issues image-branch work instead of waiting for it.
+        if os.environ.get("FTX_EAGER_INDEX_READS") == "1":   # A/B aid: block on every read as it comes
+            x0 = initial_voxelize(z, self.pres, self.vres)
+        else:
+            x0 = yield from initial_voxelize_steps(z, self.pres, self.vres)
+            yield from x0.cm.unet_levels_steps((1, 2, 4, 8, 16))
         yield "voxelized"
         x0 = self._stem(x0)
         z0 = voxel_to_point(x0, z, nearest=False)

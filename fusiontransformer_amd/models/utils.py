@@ -8,13 +8,18 @@ from __future__ import annotations
 import torch
 
 from .. import functional as spf
-from ..sparse import CoordinateManager, PointTensor, SparseTensor
+from ..sparse import CoordinateManager, HostRead, PointTensor, SparseTensor, drain
 
-__all__ = ["initial_voxelize", "point_to_voxel", "voxel_to_point"]
+__all__ = ["initial_voxelize", "initial_voxelize_steps", "point_to_voxel", "voxel_to_point"]
 
 
 def initial_voxelize(z: PointTensor, init_res, after_res) -> SparseTensor:
     """reference models/utils.py:15-35."""
+    return drain(initial_voxelize_steps(z, init_res, after_res))
+
+
+def initial_voxelize_steps(z: PointTensor, init_res, after_res):
+    """initial_voxelize as a generator that yields "sync" before the voxel count is read back (sparse.HostRead)."""
     if init_res == after_res:
         new_float_coord = z.C
     else:
@@ -22,7 +27,9 @@ def initial_voxelize(z: PointTensor, init_res, after_res) -> SparseTensor:
     floored = spf.floor_coords(new_float_coord, 1)           # torch.floor(...).int()
     pc_hash = spf.sphash(floored)
     uniq, first, cnt = spf.unique_sorted(pc_hash)            # torch.unique(pc_hash)
-    n_vox = int(cnt.item())
+    pending = HostRead(cnt)
+    yield "sync"
+    n_vox = pending.value()
     sparse_hash = uniq[:n_vox].contiguous()
     table = spf.HashTable(sparse_hash)
     idx_query = table.query(pc_hash)                         # spf.sphashquery(pc_hash, sparse_hash)

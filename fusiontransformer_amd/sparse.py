@@ -57,6 +57,16 @@ class CoordinateManager:
         km = self.kernel_maps.get(key)
         if km is not None:
             return km
+        return drain(self.kernel_map_steps(ks, cur_stride, stride))
+
+    def kernel_map_steps(self, ks, cur_stride, stride):
+        """kernel_map() as a generator: it yields "sync" after the kernels whose result sizes the next
+        arrays have been launched and before that size is read back, so a scheduler can issue other
+        work (the image branch) instead of blocking on the read (models/_fusion_common.run_fusion)."""
+        key = (ks, cur_stride, stride)
+        km = self.kernel_maps.get(key)
+        if km is not None:
+            return km
         coords = self.coords[cur_stride]
         n_in = coords.shape[0]
         table = self.table(cur_stride)
@@ -65,23 +75,95 @@ class CoordinateManager:
             out_coords = coords
         else:
             new_stride = cur_stride * stride
-            if new_stride in self.coords:
-                out_coords = self.coords[new_stride]
-            else:
-                down = Fn.downsample_coords(coords, new_stride)
-                uniq, first, cnt = Fn.unique_sorted(Fn.sphash(down))
-                n_out = int(cnt.item())  # the one host sync per level: sizes the next level's tensors
-                out_coords = Fn.gather_coords(down, first[:n_out].contiguous())
-                self.coords[new_stride] = out_coords
+            if new_stride not in self.coords:
+                yield from self.downsample_steps(cur_stride, stride)
+            out_coords = self.coords[new_stride]
         nbr = Fn.kernel_map_build(out_coords, off, table)
         pos, koff = Fn.kernel_map_count(nbr)
         # a strided kernel-2 map joins every input voxel to exactly one (parent, offset): P = N_in;
-        # for the submanifold maps the pair count is data dependent (one host sync)
-        n_pairs = n_in if (ks == stride and ks == 2) else int(koff[-1].item())
+        # for the submanifold maps the pair count is data dependent (one host read)
+        if ks == stride and ks == 2:
+            n_pairs = n_in
+        else:
+            pending = HostRead(koff[-1:])
+            yield "sync"
+            n_pairs = pending.value()
+        return self._finish_map(key, nbr, pos, koff, n_pairs, n_in, out_coords)
+
+    def _finish_map(self, key, nbr, pos, koff, n_pairs, n_in, out_coords):
         pos, pos_t, pair_in, pair_out = Fn.kernel_map_pairs(nbr, pos, n_in, n_pairs)
         km = KernelMap(nbr, pos, pos_t, pair_in, pair_out, koff, n_pairs, n_in, out_coords.shape[0], out_coords)
         self.kernel_maps[key] = km
         return km
+
+    def downsample_steps(self, cur_stride, stride):
+        """Coordinates of level cur_stride * stride (spdownsample: floor, unique in hash order)."""
+        launched = self._downsample_launch(cur_stride, stride)
+        yield "sync"
+        self._downsample_finish(cur_stride * stride, *launched)
+
+    def _downsample_launch(self, cur_stride, stride):
+        down = Fn.downsample_coords(self.coords[cur_stride], cur_stride * stride)
+        uniq, first, cnt = Fn.unique_sorted(Fn.sphash(down))
+        return down, first, HostRead(cnt)
+
+    def _downsample_finish(self, new_stride, down, first, pending):
+        n_out = pending.value()  # the one host read per level: sizes the next level's tensors
+        self.coords[new_stride] = Fn.gather_coords(down, first[:n_out].contiguous())
+
+    def unet_levels_steps(self, strides, ks=3, down_ks=2):
+        """Everything a U-Net over `strides` will ask for -- the kernel-`ks` submanifold map of every level and
+        the strided kernel-`down_ks` map between consecutive levels -- built up front.  The two data-dependent
+        sizes of a level (its pair count and the voxel count of the next level) come back in ONE host read
+        per level, after a "sync" yield."""
+        for i, s in enumerate(strides):
+            coords = self.coords[s]
+            n_in = coords.shape[0]
+            key = (ks, s, 1)
+            nbr = Fn.kernel_map_build(coords, self.offsets(ks, s, coords.device), self.table(s))
+            pos, koff = Fn.kernel_map_count(nbr)
+            last = i + 1 == len(strides)
+            if last:
+                pending = HostRead(koff[-1:])
+                yield "sync"
+                self._finish_map(key, nbr, pos, koff, pending.value(), n_in, coords)
+                break
+            ratio = strides[i + 1] // s
+            down = Fn.downsample_coords(coords, s * ratio)
+            uniq, first, cnt = Fn.unique_sorted(Fn.sphash(down))
+            pending = HostRead(torch.cat([koff[-1:].to(cnt.dtype), cnt]))
+            yield "sync"
+            n_pairs, n_out = pending.values()
+            self._finish_map(key, nbr, pos, koff, n_pairs, n_in, coords)
+            self.coords[s * ratio] = Fn.gather_coords(down, first[:n_out].contiguous())
+            drain(self.kernel_map_steps(down_ks, s, ratio))   # no host read: P = N_in
+
+
+class HostRead:
+    """A few device integers on their way to the host: the copy is queued behind the kernels that produce
+    them when the object is made, `value()` waits for that copy only."""
+
+    def __init__(self, dev: torch.Tensor):
+        self.host = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=True)
+        self.host.copy_(dev, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def values(self):
+        self.event.synchronize()
+        return [int(v) for v in self.host.tolist()]
+
+    def value(self):
+        return self.values()[0]
+
+
+def drain(steps):
+    """Run a `*_steps` generator to its end (blocking on every host read) and return its value."""
+    while True:
+        try:
+            next(steps)
+        except StopIteration as done:
+            return done.value
 
 
 class SparseTensor:
