@@ -21,6 +21,45 @@ import torch.nn.functional as F
 __all__ = ["Image2DTransformer", "image_2d_distilled_transformer"]
 
 
+_ONES = {}
+
+
+def _ones_row(m, like):
+    key = (m, like.device, like.dtype)
+    if key not in _ONES:
+        _ONES[key] = torch.ones(1, m, device=like.device, dtype=like.dtype)
+    return _ONES[key]
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b with the bias gradient as a (1, M) x (M, N) GEMM instead of autograd's sum_to reduction:
+    the column sum of a (2312, 2304..3072) gradient is 3-4x faster as a skinny GEMM on MI355X, and it keeps the
+    trunk replayable as a HIP graph (torch 2.10 / ROCm 7: the reduction kernel's result changes between the first
+    and the later replays of a captured backward, tools/probes/graph_block4.py)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x2 = x.reshape(-1, x.shape[-1])
+        ctx.save_for_backward(x2, w)
+        ctx.in_shape = x.shape
+        return torch.addmm(b, x2, w.t()).view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dx = (dy2 @ w).view(ctx.in_shape) if ctx.needs_input_grad[0] else None
+        dw = dy2.t() @ x2 if ctx.needs_input_grad[1] else None
+        db = (_ones_row(dy2.shape[0], dy2) @ dy2).view(-1) if ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def _linear(x, lin):
+    if lin.bias is None or not x.is_cuda:
+        return F.linear(x, lin.weight, lin.bias)
+    return _LinearFn.apply(x, lin.weight, lin.bias)
+
+
 class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features, drop=0.0):
         super().__init__()
@@ -30,7 +69,7 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
-        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+        return self.drop(_linear(self.drop(self.act(_linear(x, self.fc1))), self.fc2))
 
 
 class Attention(nn.Module):
@@ -47,7 +86,7 @@ class Attention(nn.Module):
 
     def forward(self, x):
         B, N, C = x.shape
-        qkv = self.qkv(x)
+        qkv = _linear(x, self.qkv)
         if self.attn_impl == "ftx":
             from .. import functional as spf
             x = spf.attention(qkv.view(B, N, 3, self.num_heads, C // self.num_heads), self.scale)
@@ -58,7 +97,7 @@ class Attention(nn.Module):
             attn = attn.softmax(dim=-1)
             attn = self.attn_drop(attn)
             x = (attn @ v).transpose(1, 2).reshape(B, N, C)
-        return self.proj_drop(self.proj(x))
+        return self.proj_drop(_linear(x, self.proj))
 
 
 class Block(nn.Module):
@@ -132,17 +171,33 @@ class Image2DTransformer(nn.Module):
         for blk in self.blocks:
             blk.attn.attn_impl = impl
 
-    def forward_blocks(self, x: torch.Tensor, on_block=None) -> Dict[str, torch.Tensor]:
-        """reference models/transformers.py:16-45: every block's output, cls/dist tokens stripped.
-        `on_block(i, tokens)` is called as soon as block i's output exists (used to lift the tapped
-        block's features while the remaining blocks are still being issued)."""
+    def _embed(self, x):
         x = self.patch_embed(x)
         cls_token = self.cls_token.expand(x.shape[0], -1, -1)
         if self.dist_token is None:
             x = torch.cat((cls_token, x), dim=1)
         else:
             x = torch.cat((cls_token, self.dist_token.expand(x.shape[0], -1, -1), x), dim=1)
-        x = self.pos_drop(x + self.pos_embed)
+        return self.pos_drop(x + self.pos_embed)
+
+    def forward_blocks(self, x: torch.Tensor, on_block=None) -> Dict[str, torch.Tensor]:
+        """reference models/transformers.py:16-45: every block's output, cls/dist tokens stripped.
+        `on_block(i, tokens)` is called as soon as block i's output exists (used to lift the tapped
+        block's features while the remaining blocks are still being issued).
+
+        With `graph_taps` set (training on the GPU) the trunk runs as one HIP graph per tapped segment --
+        forward and backward: the shapes are static, and ~500 kernel launches per step become 2 x 2 graph
+        launches.  Only the tapped blocks' outputs are returned then (the model reads no others)."""
+        graphed = self._graphed_segments(x)
+        if graphed is not None:
+            outputs = dict()
+            for last, seg in graphed:
+                x = seg(x)
+                outputs[str(last)] = x[:, self.num_tokens:, :] if self.remove_tokens_outputs else x
+                if on_block is not None:
+                    on_block(last, outputs[str(last)])
+            return outputs
+        x = self._embed(x)
         outputs = dict()
         for i, block in enumerate(self.blocks):
             if self.last_block is not None and i > self.last_block:
@@ -155,6 +210,64 @@ class Image2DTransformer(nn.Module):
             if on_block is not None:
                 on_block(i, outputs[str(i)])
         return outputs
+
+    # ---- HIP-graph execution of the trunk ------------------------------------------------------------------
+    graph_taps = None   # sorted block indices whose outputs the caller uses; None: eager execution
+
+    def _graphed_segments(self, x):
+        if not self.graph_taps or not x.is_cuda or not self.training or not torch.is_grad_enabled():
+            return None
+        cache = self.__dict__.setdefault("_graph_cache", {})
+        key = (tuple(x.shape), x.dtype, tuple(self.graph_taps), torch.cuda.current_device())
+        if key not in cache:
+            cache[key] = self._capture_segments(x)
+        return cache[key]
+
+    def _capture_segments(self, x):
+        taps = sorted(int(t) for t in self.graph_taps)
+        segments, first = [], 0
+        for t in taps:
+            segments.append(_TrunkSegment(self, first, t, embed=(first == 0)))
+            first = t + 1
+        # sample inputs with the live requires_grad pattern (the resampled image carries the gradient of sample_down)
+        samples = [(x.detach().clone().requires_grad_(x.requires_grad),)]
+        with torch.no_grad():
+            h = segments[0](samples[0][0])
+            for seg in segments[1:]:
+                samples.append((h.detach().clone().requires_grad_(True),))
+                h = seg(h)
+        graphed = torch.cuda.make_graphed_callables(tuple(segments), tuple(samples), num_warmup_iters=3)
+        # One throw-away replay of every graph.  Measured (tools/probes/graph_block.py, torch 2.10 / ROCm 7): the FIRST
+        # replay after capture returns different bias gradients for the Linear layers that follow a LayerNorm, every
+        # later replay is bit-identical to eager execution.  torch.autograd.grad leaves .grad untouched.
+        h = samples[0][0]
+        outs = []
+        for seg in graphed:
+            h = seg(h)
+            outs.append(h)
+        params = [p for p in self.parameters() if p.requires_grad]
+        torch.autograd.grad(outs[-1].sum(), params + ([samples[0][0]] if samples[0][0].requires_grad else []), allow_unused=True)
+        return list(zip(taps, graphed))
+
+
+class _TrunkSegment(nn.Module):
+    """Blocks first..last of a trunk (plus the embedding for the first segment) as one capturable callable.  It shares
+    the trunk's modules and parameters; it is never registered in the model, so state_dict keys do not change."""
+
+    def __init__(self, trunk, first, last, embed):
+        super().__init__()
+        self.embed = embed
+        if embed:
+            object.__setattr__(self, "_trunk", trunk)
+            self.patch_embed, self.cls_token, self.dist_token, self.pos_embed = trunk.patch_embed, trunk.cls_token, trunk.dist_token, trunk.pos_embed
+        self.blocks = nn.ModuleList([trunk.blocks[i] for i in range(first, last + 1)])
+
+    def forward(self, x):
+        if self.embed:
+            x = self._trunk._embed(x)
+        for block in self.blocks:
+            x = block(x)
+        return x
 
 
 def image_2d_distilled_transformer(pretrained=False, **kwargs):
