@@ -750,3 +750,40 @@ def fusion_loss(preds, seg_label, class_weights, lambda_xm, dual_head, conf3d=No
     out = _FusionLoss.apply(preds["lidar_seg_logit"], preds["img_seg_logit"], preds["lidar_seg_logit2"] if dual_head else None,
                             preds["img_seg_logit2"] if dual_head else None, seg_label.long(), class_weights, lambda_xm, conf3d, conf2d, ignore_index)
     return out[0], out[1]
+
+
+def eval_scatter_back(logits3d, logits2d, inverse, gt, class_labels, conf3d=None, conf2d=None, conf_ens=None, want_preds=True):
+    """Predictions of the model points mapped to the original points + confusion-matrix update in one kernel
+    (reference data/utils/validate.py:62-120, data/utils/evaluate.py:12-26; see include/ftx.h).
+
+    inverse (M,) int64: row of the model point of every original point (frame offset already added); gt (M,)
+    learning ids; class_labels (C,) original id of every learning id.  conf_* are (C,C) int64 accumulators.
+    Returns (pred_3d, pred_2d, pred_ens) in original label ids (None where not computed)."""
+    L = _lib.load()
+    ref = logits3d if logits3d is not None else logits2d
+    if ref is None:
+        raise ValueError("eval_scatter_back needs at least one logits tensor")
+    for t, name in ((logits3d, "logits3d"), (logits2d, "logits2d")):
+        if t is not None:
+            req(t, F32, "eval_scatter_back " + name, 2)
+    n, c = ref.shape
+    if logits3d is not None and logits2d is not None and logits3d.shape != logits2d.shape:
+        raise ValueError("eval_scatter_back: logits shapes differ")
+    req(inverse, I64, "eval_scatter_back inverse", 1)
+    gt = gt.to(I32).contiguous()
+    req(gt, I32, "eval_scatter_back gt", 1)
+    class_labels = class_labels.to(device=ref.device, dtype=I32).contiguous()
+    if class_labels.numel() != c or gt.shape[0] != inverse.shape[0]:
+        raise ValueError("eval_scatter_back: class_labels must have one id per class and gt one label per original point")
+    m = inverse.shape[0]
+    for t, name in ((conf3d, "conf3d"), (conf2d, "conf2d"), (conf_ens, "conf_ens")):
+        if t is not None:
+            req(t, I64, "eval_scatter_back " + name, 2)
+            if tuple(t.shape) != (c, c):
+                raise ValueError("eval_scatter_back: %s must be (%d, %d)" % (name, c, c))
+    mk = (lambda cond: _empty((m,), I32, ref) if (want_preds and cond) else None)
+    p3, p2, pe = mk(logits3d is not None), mk(logits2d is not None), mk(logits3d is not None and logits2d is not None)
+    bad = torch.zeros((1,), dtype=I32, device=ref.device)
+    check(L.ftx_eval_scatter_back(ptr(logits3d), ptr(logits2d), n, c, ptr(inverse), ptr(gt), m, ptr(class_labels), ptr(p3), ptr(p2), ptr(pe),
+                                  ptr(conf3d), ptr(conf2d), ptr(conf_ens), ptr(bad), stream()), "ftx_eval_scatter_back")
+    return p3, p2, pe, bad

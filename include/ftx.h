@@ -215,6 +215,17 @@ int ftx_attn_bwd(const float *qkv, const float *out, const float *grad_out, cons
 size_t ftx_fusion_loss_workspace_bytes(void);
 int ftx_fusion_loss(const float *lidar_logit, const float *img_logit, const float *lidar_logit2, const float *img_logit2, const int64_t *label, const float *class_weights, float lambda_xm, int64_t n, int32_t c, int32_t ignore_index, float *losses, float *grad_lidar, float *grad_img, float *grad_lidar2, float *grad_img2, int64_t *conf3d, int64_t *conf2d, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- evaluation scatter-back: data/utils/validate.py:62-120 + data/utils/evaluate.py:12-26 ----
+ * For every ORIGINAL point i (m of them, all frames of the batch concatenated): r = inverse[i] is the row of the
+ * model point (voxel) it was quantised into (inverse_map of its frame + the frame's row offset, map_sparse_to_org);
+ * pred_3d = argmax(logits3d[r]), pred_2d = argmax(logits2d[r]), pred_ens = argmax(softmax(logits2d[r]) +
+ * softmax(logits3d[r])) (first maximum wins); predictions are written as ORIGINAL label ids class_labels[pred]
+ * (map_inverse_label).  gt (m) holds learning ids; as in Evaluator.update an original id 0 is replaced by
+ * num_classes, and a point only counts if that id occurs in class_labels.  conf_* (c,c) int64 are ACCUMULATED:
+ * conf[index of gt id][index of pred id] += 1.  Either logits pointer, any pred_* / conf_* pointer may be NULL.
+ * *bad_flag is set to 1 if an inverse index or a gt id is out of range (those points are skipped). c <= 32. */
+int ftx_eval_scatter_back(const float *logits3d, const float *logits2d, int64_t n_rows, int32_t num_classes, const int64_t *inverse, const int32_t *gt, int64_t m, const int32_t *class_labels, int32_t *pred3d, int32_t *pred2d, int32_t *pred_ens, int64_t *conf3d, int64_t *conf2d, int64_t *conf_ens, int32_t *bad_flag, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

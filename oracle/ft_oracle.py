@@ -755,3 +755,42 @@ def confusion_matrix(logits, labels, num_classes, ignore_index=0):
 def iou_from_matrix(mat):
     h = mat.float()
     return torch.diag(h) / (h.sum(1) + h.sum(0) - torch.diag(h))
+
+
+# ---------------------------------------------------------------------------------------------
+# evaluation scatter-back
+# ---------------------------------------------------------------------------------------------
+def validate_batch(lidar_logit, img_logit, inverse_maps, orig_seg_labels, n_vox, class_labels):
+    """Per-batch body of data/utils/validate.py:62-120 with USE_FUSION, numpy.
+
+    argmax / softmax-sum ensemble per model point (validate.py:62-72), `x[inverse_map]` per frame
+    (map_sparse_to_org, validate.py:10-11,93-103), label inverse map (validate.py:105-113,
+    semantic_kitti_dataloader.py:92), and Evaluator.update (data/utils/evaluate.py:12-26): gt id 0 becomes
+    num_classes, then sklearn's confusion_matrix(gt, pred, labels=class_labels) -- entries whose gt or pred id is
+    not in `labels` are dropped, rows are gt, columns pred.
+    Returns (pred_3d, pred_2d, pred_ens) per original point in original ids and the three matrices."""
+    l3 = np.asarray(lidar_logit, dtype=np.float32)
+    l2 = np.asarray(img_logit, dtype=np.float32)
+    class_labels = np.asarray(class_labels)
+    c = len(class_labels)
+    v3, v2 = l3.argmax(1), l2.argmax(1)
+    def softmax(x):
+        e = np.exp(x - x.max(1, keepdims=True), dtype=np.float32)
+        return e / e.sum(1, keepdims=True, dtype=np.float32)
+    ve = (softmax(l2) + softmax(l3)).argmax(1)
+    index_of = {int(lab): i for i, lab in reversed(list(enumerate(class_labels)))}
+    mats = [np.zeros((c, c)) for _ in range(3)]
+    outs = [[], [], []]
+    left = 0
+    for b, (inv, gt) in enumerate(zip(inverse_maps, orig_seg_labels)):
+        right = left + int(n_vox[b])
+        gt_o = class_labels[np.asarray(gt)].copy()
+        gt_o[gt_o == 0] = c
+        for k, v in enumerate((v3, v2, ve)):
+            pred_o = class_labels[v[left:right][np.asarray(inv)]]
+            outs[k].append(pred_o)
+            for g, p in zip(gt_o, pred_o):
+                if int(g) in index_of and int(p) in index_of:
+                    mats[k][index_of[int(g)], index_of[int(p)]] += 1
+        left = right
+    return [np.concatenate(o) for o in outs], mats

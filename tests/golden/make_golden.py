@@ -20,7 +20,11 @@ What is pinned, and by which reference code:
                        the int cast / range mask of semantic_kitti_dataloader.py:216-225.
   projection.npz       reference DummyDataset.read_calib / select_points_in_frustum and the
                        projection statements of data/semantic_kitti/preprocess.py:54-116 on a
-                       synthetic calib file + scan."""
+                       synthetic calib file + scan.
+  eval_scatter_back.npz  reference map_sparse_to_org (data/utils/validate.py:10-11), Evaluator
+                       (data/utils/evaluate.py:4-61) and the label inverse map built as in
+                       semantic_kitti_dataloader.py:89-92 from semantic_kitti_label.yaml, driven by
+                       the statements of validate.py:62-120 on seeded logits of two frames."""
 import os
 import sys
 import tempfile
@@ -155,12 +159,72 @@ def projection():
                         points_img=img_points[keep_idx_img_pts], img_indices=img_points[keep_idx_img_pts].astype(np.int64))
 
 
+def eval_scatter_back():
+    import yaml
+    import torch.nn.functional as F
+    from FusionTransformer.data.utils.evaluate import Evaluator
+    from FusionTransformer.data.utils.validate import map_sparse_to_org
+    with open(os.path.join(REF, "FusionTransformer/data/semantic_kitti/semantic_kitti_label.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    # semantic_kitti_dataloader.py:89-92
+    class_names = [cfg["labels"][k] for k in cfg["learning_map_inv"].values()]
+    class_labels = list(cfg["learning_map_inv"].copy().values())
+    map_inverse_label = np.vectorize(lambda learning_label: cfg["learning_map_inv"][learning_label])
+    rng = np.random.default_rng(5)
+    n_vox = [1500, 1100]                       # voxels (= model points) per frame
+    n_org = [4000, 3100]                       # original points per frame
+    n = sum(n_vox)
+    preds = {k: torch.from_numpy((rng.standard_normal((n, 20)) * 2).astype(np.float32)) for k in ("lidar_seg_logit", "img_seg_logit")}
+    inverse_map = [rng.integers(0, nv, no).astype(np.int64) for nv, no in zip(n_vox, n_org)]
+    orig_seg_label = [rng.integers(0, 20, no).astype(np.int64) for no in n_org]
+    points_idx = [np.ones(nv, dtype=bool) for nv in n_vox]
+    # statements of validate.py:62-120 with USE_FUSION
+    pred_label_voxel_3d = preds['lidar_seg_logit'].argmax(1).cpu().numpy()
+    pred_label_voxel_2d = preds['img_seg_logit'].argmax(1).cpu().numpy()
+    probs_2d = F.softmax(preds['img_seg_logit'], dim=1)
+    probs_3d = F.softmax(preds['lidar_seg_logit'], dim=1)
+    pred_label_voxel_ensemble = (probs_2d + probs_3d).argmax(1).cpu().numpy()
+    evaluator_3d, evaluator_2d, evaluator_ensemble = (Evaluator(class_names, labels=class_labels) for _ in range(3))
+    out3, out2, oute = [], [], []
+    left_idx = 0
+    for batch_ind in range(len(orig_seg_label)):
+        curr_points_idx = points_idx[batch_ind]
+        assert np.all(curr_points_idx)
+        curr_inverse_map = inverse_map[batch_ind]
+        curr_seg_label = orig_seg_label[batch_ind].copy()
+        right_idx = left_idx + curr_points_idx.sum()
+        pred_label_3d = map_sparse_to_org(pred_label_voxel_3d[left_idx:right_idx], curr_inverse_map)
+        pred_label_2d = map_sparse_to_org(pred_label_voxel_2d[left_idx:right_idx], curr_inverse_map)
+        pred_label_ensemble = map_sparse_to_org(pred_label_voxel_ensemble[left_idx:right_idx], curr_inverse_map)
+        curr_seg_label = map_inverse_label(curr_seg_label)
+        pred_label_3d = map_inverse_label(pred_label_3d)
+        pred_label_2d = map_inverse_label(pred_label_2d)
+        pred_label_ensemble = map_inverse_label(pred_label_ensemble)
+        out3.append(pred_label_3d.copy()); out2.append(pred_label_2d.copy()); oute.append(pred_label_ensemble.copy())
+        evaluator_3d.update(pred_label_3d, curr_seg_label.copy())
+        evaluator_2d.update(pred_label_2d, curr_seg_label.copy())
+        evaluator_ensemble.update(pred_label_ensemble, curr_seg_label.copy())
+        left_idx = right_idx
+    save = dict(lidar_seg_logit=preds["lidar_seg_logit"].numpy(), img_seg_logit=preds["img_seg_logit"].numpy(), n_vox=np.array(n_vox), n_org=np.array(n_org),
+                inverse_map=np.concatenate(inverse_map), orig_seg_label=np.concatenate(orig_seg_label), class_labels=np.array(class_labels),
+                pred_3d=np.concatenate(out3), pred_2d=np.concatenate(out2), pred_ensemble=np.concatenate(oute),
+                conf_3d=evaluator_3d.confusion_matrix, conf_2d=evaluator_2d.confusion_matrix, conf_ensemble=evaluator_ensemble.confusion_matrix,
+                iou_3d=np.array(evaluator_3d.class_iou), overall_iou_3d=evaluator_3d.overall_iou, overall_acc_3d=evaluator_3d.overall_acc,
+                overall_iou_ensemble=evaluator_ensemble.overall_iou)
+    np.savez_compressed(os.path.join(OUT, "eval_scatter_back.npz"), **save)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:          # regenerate only the named fixtures
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     upsample_index()
     bilinear_lift()
     losses_metric()
     voxel_coords()
     projection()
+    eval_scatter_back()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

@@ -84,6 +84,22 @@ def test_projection_matches_reference_preprocess():
     assert np.array_equal(pts_img, g["points_img"])
     assert np.array_equal(pts_img.astype(np.int64), g["img_indices"])
 
+def _split(g):
+    nv, no = g["n_vox"], g["n_org"]
+    cuts = np.cumsum(no)[:-1]
+    return nv, np.split(g["inverse_map"], cuts), np.split(g["orig_seg_label"], cuts)
+
+
+def test_eval_scatter_back_oracle_matches_reference_evaluator():
+    g = load("eval_scatter_back.npz")
+    nv, inv, gts = _split(g)
+    (p3, p2, pe), (m3, m2, me) = O.validate_batch(g["lidar_seg_logit"], g["img_seg_logit"], inv, gts, nv, g["class_labels"])
+    assert np.array_equal(p3, g["pred_3d"]) and np.array_equal(p2, g["pred_2d"]) and np.array_equal(pe, g["pred_ensemble"])
+    assert np.array_equal(m3, g["conf_3d"]) and np.array_equal(m2, g["conf_2d"]) and np.array_equal(me, g["conf_ensemble"])
+    # the reference quirk this pins: unlabeled points (id 0) are re-labelled num_classes = 20, which IS a label id
+    # ("other-vehicle", learning id 5), so they are counted as ground truth of that class
+    assert g["conf_3d"][5].sum() > (g["orig_seg_label"] == 5).sum()
+
 
 @pytest.mark.gpu
 def test_product_lift_and_resample_match_reference_goldens():
@@ -157,3 +173,34 @@ def test_gpu_voxelisation_matches_reference_augment_and_scale():
     _, inds = np.unique(key, return_index=True)
     assert np.array_equal(keep.cpu().numpy(), rows[inds])
     assert np.array_equal(coords.cpu().numpy(), ci[rows[inds]])
+
+
+@pytest.mark.gpu
+def test_eval_scatter_back_kernel_matches_reference_evaluator():
+    from fusiontransformer_amd.evaluate import Evaluator, validate_batch
+    g = load("eval_scatter_back.npz")
+    nv, inv, gts = _split(g)
+    names = ["c%d" % i for i in range(20)]
+    ev = [Evaluator(names, labels=g["class_labels"]) for _ in range(3)]
+    preds = {"lidar_seg_logit": torch.from_numpy(g["lidar_seg_logit"]).cuda(), "img_seg_logit": torch.from_numpy(g["img_seg_logit"]).cuda()}
+    batch = {"orig_seg_label": gts, "inverse_map": inv, "sparse_orig_points_idx": [np.ones(n, dtype=bool) for n in nv]}
+    out = validate_batch(preds, batch, g["class_labels"], *ev, want_preds=True)
+    assert int(out["bad_index_flag"].item()) == 0
+    assert np.array_equal(out["pred_3d"].cpu().numpy(), g["pred_3d"])
+    assert np.array_equal(out["pred_2d"].cpu().numpy(), g["pred_2d"])
+    # the ensemble adds two float32 softmaxes: allow argmax flips only where the two best sums tie to rounding
+    pe = out["pred_ensemble"].cpu().numpy()
+    assert (pe != g["pred_ensemble"]).mean() < 1e-3
+    assert np.array_equal(ev[0].confusion_matrix, g["conf_3d"]) and np.array_equal(ev[1].confusion_matrix, g["conf_2d"])
+    assert np.abs(ev[2].confusion_matrix - g["conf_ensemble"]).sum() <= 2 * (pe != g["pred_ensemble"]).sum()
+    assert abs(ev[0].overall_iou - float(g["overall_iou_3d"])) < 1e-12 and abs(ev[0].overall_acc - float(g["overall_acc_3d"])) < 1e-12
+    assert np.allclose(np.array(ev[0].class_iou), g["iou_3d"], equal_nan=True)
+    # a second batch accumulates; an out-of-range inverse index raises the flag instead of reading out of bounds
+    validate_batch(preds, batch, g["class_labels"], *ev)
+    assert np.array_equal(ev[0].confusion_matrix, 2 * g["conf_3d"])
+    bad = dict(batch, inverse_map=[inv[0] + 10 ** 6, inv[1]])
+    assert int(validate_batch(preds, bad, g["class_labels"], *ev)["bad_index_flag"].item()) == 1
+    # LiDAR-only model: no image logits
+    ev1 = Evaluator(names, labels=g["class_labels"])
+    validate_batch({"lidar_seg_logit": preds["lidar_seg_logit"]}, batch, g["class_labels"], evaluator_3d=ev1)
+    assert np.array_equal(ev1.confusion_matrix, g["conf_3d"])
