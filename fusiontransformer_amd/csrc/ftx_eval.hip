@@ -91,3 +91,40 @@ extern "C" int ftx_eval_scatter_back(const float *logits3d, const float *logits2
                                                        bad_flag);
   return check_launch("ftx_eval_scatter_back");
 }
+
+// ---------------------------------------------------------------------------------------
+// Offline LiDAR -> image projection (data/semantic_kitti/preprocess.py:108-116): homogeneous point times the 3x4
+// float32 matrix P2 * Tr, perspective divide, frustum test 0 < u < width, 0 < v < height.  keep[i] = 1 for
+// points in front of the vehicle (x > 0) that land inside the image; rowcol[i] = (v, u) (the reference's fliplr).
+// The dot product is accumulated k = 0..3 with fused multiply-adds, the order of the host BLAS the reference
+// calls through numpy (the golden vectors of tests/golden/projection.npz are reproduced bit for bit).
+// ---------------------------------------------------------------------------------------
+__global__ void project_points_kernel(const float *__restrict__ pts, int64_t n, const float *__restrict__ P, float width, float height,
+                                      uint8_t *__restrict__ keep, float *__restrict__ rowcol) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    float h[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      float acc = P[4 * r] * x;
+      acc = fmaf(P[4 * r + 1], y, acc);
+      acc = fmaf(P[4 * r + 2], z, acc);
+      acc = fmaf(P[4 * r + 3], 1.0f, acc);
+      h[r] = acc;
+    }
+    const float u = h[0] / h[2], v = h[1] / h[2];
+    const bool in = (x > 0.f) && (u > 0.f) && (v > 0.f) && (u < width) && (v < height);
+    keep[i] = in ? 1 : 0;
+    rowcol[2 * i] = v;
+    rowcol[2 * i + 1] = u;
+  }
+}
+
+extern "C" int ftx_project_points(const float *points, int64_t n, const float *proj_matrix, int32_t width, int32_t height, uint8_t *keep,
+                                  float *rowcol, void *stream) {
+  FTX_REQUIRE(n >= 0 && width > 0 && height > 0, "ftx_project_points: bad size");
+  if (n == 0) return FTX_OK;
+  FTX_REQUIRE(points && proj_matrix && keep && rowcol, "ftx_project_points: null pointer");
+  project_points_kernel<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(points, n, proj_matrix, (float)width, (float)height, keep, rowcol);
+  return check_launch("ftx_project_points");
+}

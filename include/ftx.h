@@ -226,6 +226,12 @@ int ftx_fusion_loss(const float *lidar_logit, const float *img_logit, const floa
  * *bad_flag is set to 1 if an inverse index or a gt id is out of range (those points are skipped). c <= 32. */
 int ftx_eval_scatter_back(const float *logits3d, const float *logits2d, int64_t n_rows, int32_t num_classes, const int64_t *inverse, const int32_t *gt, int64_t m, const int32_t *class_labels, int32_t *pred3d, int32_t *pred2d, int32_t *pred_ens, int64_t *conf3d, int64_t *conf2d, int64_t *conf_ens, int32_t *bad_flag, void *stream);
 
+/* ---- offline LiDAR -> image projection: data/semantic_kitti/preprocess.py:108-116 ----
+ * points (n,3) float32 in the LiDAR frame, proj_matrix (3,4) float32 = P2 * Tr (preprocess.py:32-33).
+ * keep[i] = 1 iff x > 0 and 0 < u < width and 0 < v < height (select_points_in_frustum, preprocess.py:75-91);
+ * rowcol (n,2) = (v, u) for EVERY point (the caller compacts with keep), i.e. the reference's fliplr(img_points). */
+int ftx_project_points(const float *points, int64_t n, const float *proj_matrix, int32_t width, int32_t height, uint8_t *keep, float *rowcol, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

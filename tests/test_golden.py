@@ -204,3 +204,22 @@ def test_eval_scatter_back_kernel_matches_reference_evaluator():
     ev1 = Evaluator(names, labels=g["class_labels"])
     validate_batch({"lidar_seg_logit": preds["lidar_seg_logit"]}, batch, g["class_labels"], evaluator_3d=ev1)
     assert np.array_equal(ev1.confusion_matrix, g["conf_3d"])
+
+
+@pytest.mark.gpu
+def test_projection_kernel_matches_reference_preprocess():
+    from fusiontransformer_amd.data.preprocess import project_points, project_scan
+    g = load("projection.npz")
+    pts = torch.from_numpy(g["points"]).cuda()
+    keep, rowcol = project_points(pts, torch.from_numpy(g["proj_matrix"]).cuda(), 1226, 370)
+    keep = keep.cpu().numpy()
+    assert np.array_equal(keep, g["keep_idx"])
+    got = rowcol.cpu().numpy()[keep]
+    assert np.array_equal(got.astype(np.int64), g["img_indices"])          # the pixel every point lifts from: exact
+    assert np.array_equal(got, g["points_img"])                             # and the float coordinates bit for bit
+    scan = np.concatenate([g["points"], np.linspace(0, 1, len(g["points"]), dtype=np.float32)[:, None]], 1)
+    labels = (np.arange(len(scan)) % 20).astype(np.uint32) | np.uint32(7 << 16)   # upper half = instance id, dropped
+    d = project_scan(scan, labels, g["proj_matrix"], (1226, 370))
+    assert np.array_equal(d["points"], g["points"][g["keep_idx"]]) and np.array_equal(d["feats"], scan[g["keep_idx"]])
+    assert d["seg_label"].dtype == np.int16 and np.array_equal(d["seg_label"], (np.arange(len(scan)) % 20)[g["keep_idx"]])
+    assert np.array_equal(d["points_img"], g["points_img"])

@@ -89,3 +89,30 @@ def test_product_path_refuses_cpu_tensors():
         spf.sphash(torch.zeros((4, 4), dtype=torch.int32))
     with pytest.raises(ValueError):
         spf.spvoxelize(torch.zeros(4, 4), torch.zeros(4, dtype=torch.int32), torch.ones(2, dtype=torch.int32))
+
+
+def test_scan_file_round_trip_and_untrusted_pickles_are_refused(tmp_path):
+    """The reference's per-scan pickle (preprocess.py:150-163) reads back; anything else in a .pkl is refused."""
+    import pickle
+    from fusiontransformer_amd.data.preprocess import read_scan, write_scan
+    rng = np.random.default_rng(0)
+    scan = {"points": rng.standard_normal((50, 3)).astype(np.float32), "feats": rng.standard_normal((50, 4)).astype(np.float32),
+            "seg_labels": rng.integers(0, 20, 50).astype(np.int16), "points_img": rng.uniform(0, 300, (50, 2)).astype(np.float32),
+            "lidar_path": "sequences/08/velodyne/000000.bin", "camera_path": "sequences/08/image_2/000000.png", "image_size": (1226, 370)}
+    p = tmp_path / "0.pkl"
+    write_scan(p, scan)
+    back = read_scan(p)
+    for k in ("points", "feats", "seg_labels", "points_img"):
+        assert back[k].dtype == scan[k].dtype and np.array_equal(back[k], scan[k])
+    assert back["image_size"] == (1226, 370) and back["lidar_path"] == scan["lidar_path"]
+    with open(p, "rb") as f:                          # a file written the reference's way (plain pickle.dump) is the same bytes
+        assert pickle.load(f).keys() == back.keys()
+    evil = tmp_path / "evil.pkl"
+    with open(evil, "wb") as f:
+        pickle.dump({"points": print}, f)            # a global that is not a numpy constructor
+    with pytest.raises(pickle.UnpicklingError):
+        read_scan(evil)
+    bad = tmp_path / "bad.pkl"
+    write_scan(bad, dict(scan, points=scan["points"][:10]))
+    with pytest.raises(ValueError):
+        read_scan(bad)
