@@ -157,6 +157,9 @@ def main():
     ap.add_argument("--kind", default="middle", choices=["middle", "early", "late"])
     ap.add_argument("--attn", default=os.environ.get("FTX_ATTN", "ftx"), choices=["ftx", "torch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial-branches", action="store_true",
+                    help="issue the image and LiDAR branches back to back on one stream in every step (profiling aid: under rocprofv3 "
+                         "each kernel's duration is then its own, as in the roofline block's HIP-event timings)")
     ap.add_argument("--no-tune-gemm", dest="tune_gemm", action="store_false", help="skip TunableOp selection of the library GEMM kernels")
     args = ap.parse_args()
 
@@ -211,6 +214,7 @@ def main():
     barrier()
     if rank == 0:
         log("timing %d steps" % args.steps)
+    model.overlap_branches = not args.serial_branches
     t0 = time.perf_counter()
     launch_log = None
     for i in range(args.steps):
@@ -222,7 +226,7 @@ def main():
             model.overlap_branches = False
         step(data)
     spf.LAUNCH_LOG = None
-    model.overlap_branches = True
+    model.overlap_branches = not args.serial_branches
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -243,7 +247,7 @@ def main():
                                    "%d points/batch, %sFusionTransformer (DeiT-B/16-384 distilled + SPVCNN), fwd+loss+bwd+Adam, fp32, random-init weights"
                                    % (args.shape, SHAPES[args.shape]["H"], SHAPES[args.shape]["W"], n_points, args.kind.capitalize()),
                        "frames_per_gpu": args.batch, "global_batch": args.batch * world, "points_per_gpu_batch": n_points,
-                       "attention": args.attn, "library_gemm_tuning": bool(args.tune_gemm), "branch_overlap": "2 HIP streams (image / LiDAR)",
+                       "attention": args.attn, "library_gemm_tuning": bool(args.tune_gemm), "branch_overlap": "off (--serial-branches)" if args.serial_branches else "2 HIP streams (image / LiDAR)",
                        "parallelism": "dp%d" % world},
             "frames_per_sec_per_gpu": round(frames / elapsed / world, 3),
             "roofline": roof,

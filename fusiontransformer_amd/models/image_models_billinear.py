@@ -117,12 +117,13 @@ class Net2DBillinear(nn.Module):
             new_state_dict = OrderedDict((k.replace("backbone.", ""), v) for k, v in ckpt.items() if "backbone" in k)
             self.backbone.load_state_dict(new_state_dict)
         self.backbone.set_attention_impl(kw.get("attn_impl", "ftx"))
-        # Opt-in (vit_graphs=True or FTX_VIT_GRAPHS=1): training on the GPU runs the trunk as HIP graphs, one per tapped
-        # segment (transformers.py).  Worth +26-30 % frames/s at batch 1-2 where the host is the limit, +1 % at batch 4.
-        # Not the default: on torch 2.10 / ROCm 7 capturing a module whose parameters already went through an eager
-        # backward crashes in hipStreamEndCapture (tools/probes/graph_recapture.py), so the first training forward must
-        # be the capturing one.
-        if kw.get("vit_graphs", os.environ.get("FTX_VIT_GRAPHS", "0") == "1") and self.late_feat_block_number is not None:
+        # Training on the GPU runs the trunk as HIP graphs, one per tapped segment (transformers.py): ~500 kernel launches
+        # per step become 4 graph launches, which takes 7 ms off the host side of a step (batch 4: the host issue time
+        # drops from ~24 to ~17 ms, so the step stays GPU-bound on a slow host; +26-30 % frames/s at batch 1-2).
+        # vit_graphs=False or FTX_VIT_GRAPHS=0 turns it off.  Known limit (torch 2.10 / ROCm 7): capturing a module whose
+        # parameters already went through an EAGER backward crashes in hipStreamEndCapture
+        # (tools/probes/graph_recapture.py) -- so do not switch it on in the middle of a run.
+        if kw.get("vit_graphs", os.environ.get("FTX_VIT_GRAPHS", "1") != "0") and self.late_feat_block_number is not None:
             self.backbone.graph_taps = sorted({int(self.late_feat_block_number)} | ({int(self.middle_feat_block_number)} if self.middle_feat_block_number else set()))
         # Parameters that can never receive a gradient (the reference needs
         # find_unused_parameters=True for them, TorchpackInterface.py:81): the final `norm`
