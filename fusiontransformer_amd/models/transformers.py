@@ -191,11 +191,12 @@ class Image2DTransformer(nn.Module):
         graphed = self._graphed_segments(x)
         if graphed is not None:
             outputs = dict()
-            for last, seg in graphed:
+            for last, seg, is_tap in graphed:
                 x = seg(x)
-                outputs[str(last)] = x[:, self.num_tokens:, :] if self.remove_tokens_outputs else x
-                if on_block is not None:
-                    on_block(last, outputs[str(last)])
+                if is_tap:
+                    outputs[str(last)] = x[:, self.num_tokens:, :] if self.remove_tokens_outputs else x
+                    if on_block is not None:
+                        on_block(last, outputs[str(last)])
             return outputs
         x = self._embed(x)
         outputs = dict()
@@ -213,6 +214,7 @@ class Image2DTransformer(nn.Module):
 
     # ---- HIP-graph execution of the trunk ------------------------------------------------------------------
     graph_taps = None   # sorted block indices whose outputs the caller uses; None: eager execution
+    graph_segment_blocks = 3
 
     def _graphed_segments(self, x):
         if not self.graph_taps or not x.is_cuda or not self.training or not torch.is_grad_enabled():
@@ -225,10 +227,20 @@ class Image2DTransformer(nn.Module):
 
     def _capture_segments(self, x):
         taps = sorted(int(t) for t in self.graph_taps)
-        segments, first = [], 0
+        # segment ends: every tap, and at most `graph_segment_blocks` blocks per graph -- the gradients of a segment become
+        # available together when its backward graph has run, so shorter segments keep the data-parallel bucket
+        # all-reduces (dist.GradReducer) overlapped with the rest of the backward
+        ends, first = [], 0
         for t in taps:
-            segments.append(_TrunkSegment(self, first, t, embed=(first == 0)))
+            while t - first + 1 > self.graph_segment_blocks:
+                ends.append(first + self.graph_segment_blocks - 1)
+                first = ends[-1] + 1
+            ends.append(t)
             first = t + 1
+        segments, first = [], 0
+        for e in ends:
+            segments.append(_TrunkSegment(self, first, e, embed=(first == 0)))
+            first = e + 1
         # sample inputs with the live requires_grad pattern (the resampled image carries the gradient of sample_down)
         samples = [(x.detach().clone().requires_grad_(x.requires_grad),)]
         with torch.no_grad():
@@ -237,17 +249,8 @@ class Image2DTransformer(nn.Module):
                 samples.append((h.detach().clone().requires_grad_(True),))
                 h = seg(h)
         graphed = torch.cuda.make_graphed_callables(tuple(segments), tuple(samples), num_warmup_iters=3)
-        # One throw-away replay of every graph.  Measured (tools/probes/graph_block.py, torch 2.10 / ROCm 7): the FIRST
-        # replay after capture returns different bias gradients for the Linear layers that follow a LayerNorm, every
-        # later replay is bit-identical to eager execution.  torch.autograd.grad leaves .grad untouched.
-        h = samples[0][0]
-        outs = []
-        for seg in graphed:
-            h = seg(h)
-            outs.append(h)
-        params = [p for p in self.parameters() if p.requires_grad]
-        torch.autograd.grad(outs[-1].sum(), params + ([samples[0][0]] if samples[0][0].requires_grad else []), allow_unused=True)
-        return list(zip(taps, graphed))
+        taps_set = set(taps)
+        return [(e, g, e in taps_set) for e, g in zip(ends, graphed)]
 
 
 class _TrunkSegment(nn.Module):
