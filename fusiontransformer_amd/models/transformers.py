@@ -222,7 +222,13 @@ class Image2DTransformer(nn.Module):
         cache = self.__dict__.setdefault("_graph_cache", {})
         key = (tuple(x.shape), x.dtype, tuple(self.graph_taps), torch.cuda.current_device())
         if key not in cache:
-            cache[key] = self._capture_segments(x)
+            try:
+                cache[key] = self._capture_segments(x)
+            except Exception as err:   # capture refused (another thread touched the device, unsupported op, ...): run eagerly
+                import sys
+                print("[fusiontransformer_amd] HIP-graph capture of the ViT trunk failed (%s: %s); running it eagerly" % (type(err).__name__, err),
+                      file=sys.stderr, flush=True)
+                cache[key] = None
         return cache[key]
 
     def _capture_segments(self, x):
