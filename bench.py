@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--kind", default="middle", choices=["middle", "early", "late"])
     ap.add_argument("--attn", default=os.environ.get("FTX_ATTN", "ftx"), choices=["ftx", "torch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batch1", action="store_true", help="skip the secondary measurement at batch 1 (the literal BASELINE configs[1] frame)")
     ap.add_argument("--serial-branches", action="store_true",
                     help="issue the image and LiDAR branches back to back on one stream in every step (profiling aid: under rocprofv3 "
                          "each kernel's duration is then its own, as in the roofline block's HIP-event timings)")
@@ -252,6 +253,19 @@ def main():
             "frames_per_sec_per_gpu": round(frames / elapsed / world, 3),
             "roofline": roof,
         }
+        if world == 1 and args.batch != 1 and not args.no_batch1:
+            # secondary figure, outside the timed region above: the literal BASELINE configs[1] workload (ONE frame per step)
+            _, one = build_inputs(cfg, 1, args.shape, rank, device)
+            for _ in range(3):
+                step(one)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                step(one)
+            torch.cuda.synchronize()
+            ms1 = 1e3 * (time.perf_counter() - t1) / 10
+            out["config"]["batch1_configs1_literal"] = {"frames_per_sec": round(1e3 / ms1, 2), "ms_per_step": round(ms1, 3), "steps": 10,
+                                                       "points": int(one["lidar"].F.shape[0])}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, np_batch)
         print(json.dumps(out), flush=True)
