@@ -189,3 +189,71 @@ def test_two_stream_overlap_is_bit_identical_to_serial_issue():
             assert torch.equal(outs[k], results[0][0][k]), k
         for n in grads:
             assert torch.equal(grads[n], results[0][1][n]), n
+
+
+def test_graphed_trunk_is_bit_identical_to_eager_execution():
+    """The ViT trunk as HIP graphs (default) against the same model run eagerly: same logits, same gradients, bit for
+    bit, on the capturing step and on later replays."""
+    from fusiontransformer_amd.data.synth import make_batch
+    from fusiontransformer_amd.trainer import fusion_losses
+    pin = product_inputs(make_batch([2, 3], max_points=3000))
+
+    def run(graphs, steps):
+        cfg, oracle, model, _ = _pair("middle", seed=5)
+        model.train()
+        model.image_backbone.backbone.graph_taps = model.image_backbone.backbone.graph_taps if graphs else None
+        if graphs:
+            assert model.image_backbone.backbone.graph_taps, "graphs are expected to be the default"
+        out_all = []
+        for _ in range(steps):
+            model.zero_grad(set_to_none=True)
+            torch.manual_seed(0)
+            out = model(pin)
+            l2, l3 = fusion_losses(out, pin["seg_label"], None, 0.1, True)
+            (l2 + l3).backward()
+            torch.cuda.synchronize()
+            out_all.append(({k: v.detach().clone() for k, v in out.items()}, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+        if graphs:
+            assert model.image_backbone.backbone.__dict__.get("_graph_cache"), "the trunk was not captured"
+            assert all(v is not None for v in model.image_backbone.backbone._graph_cache.values()), "capture fell back to eager"
+        return out_all
+
+    eager = run(False, 1)[0]
+    for outs, grads in run(True, 3):
+        for k in eager[0]:
+            assert torch.equal(outs[k], eager[0][k]), k
+        assert grads.keys() == eager[1].keys()
+        for n in grads:
+            assert torch.equal(grads[n], eager[1][n]), n
+
+
+def test_deferred_index_build_equals_lazy_build():
+    """CoordinateManager.unet_levels_steps (all maps up front, sizes read back after a yield) against the lazy
+    kernel_map() calls it replaces: identical coordinates, pair lists and offsets at every level."""
+    from fusiontransformer_amd.data.synth import make_batch
+    from fusiontransformer_amd.models.utils import initial_voxelize
+    from fusiontransformer_amd.sparse import PointTensor, drain
+    b = make_batch([0, 1], max_points=4000)
+    feats, coords = torch.from_numpy(b["feats"]).cuda(), torch.from_numpy(b["coords"]).float().cuda()
+    cm_a = initial_voxelize(PointTensor(feats, coords), 1, 1).cm
+    tokens = []
+    gen = cm_a.unet_levels_steps((1, 2, 4, 8, 16))
+    try:
+        while True:
+            tokens.append(next(gen))
+    except StopIteration:
+        pass
+    assert tokens == ["sync"] * 5
+    cm_b = initial_voxelize(PointTensor(feats, coords), 1, 1).cm
+    for s in (1, 2, 4, 8):
+        cm_b.kernel_map(3, s, 1)
+        cm_b.kernel_map(2, s, 2)
+    cm_b.kernel_map(3, 16, 1)
+    assert cm_a.kernel_maps.keys() == cm_b.kernel_maps.keys()
+    for s in (1, 2, 4, 8, 16):
+        assert torch.equal(cm_a.coords[s], cm_b.coords[s]), s
+    for key, ka in cm_a.kernel_maps.items():
+        kb = cm_b.kernel_maps[key]
+        assert (ka.n_pairs, ka.n_in, ka.n_out) == (kb.n_pairs, kb.n_in, kb.n_out), key
+        for f in ("nbr", "pos", "pos_t", "pair_in", "pair_out", "koff"):
+            assert torch.equal(getattr(ka, f), getattr(kb, f)), (key, f)
