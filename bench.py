@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--kind", default="middle", choices=["middle", "early", "late"])
     ap.add_argument("--attn", default=os.environ.get("FTX_ATTN", "ftx"), choices=["ftx", "torch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bf16-forward", action="store_true",
+                    help="BASELINE configs[4]: ViT GEMMs with bf16 operands (fp32 accumulate); NOT the headline configuration, the line says so in dtype")
     ap.add_argument("--no-batch1", action="store_true", help="skip the secondary measurement at batch 1 (the literal BASELINE configs[1] frame)")
     ap.add_argument("--serial-branches", action="store_true",
                     help="issue the image and LiDAR branches back to back on one stream in every step (profiling aid: under rocprofv3 "
@@ -198,6 +200,8 @@ def main():
     torch.manual_seed(0)
     model, m2d, m3d = build_model(cfg)
     model = model.to(device).train()
+    if args.bf16_forward:
+        model.image_backbone.backbone.set_bf16(True)
     reducer = GradReducer(model) if world > 1 else None
     step = TrainStep(cfg, model, metrics=(m2d, m3d), grad_reducer=reducer)
     np_batch, data = build_inputs(cfg, args.batch, args.shape, rank, device)
@@ -243,7 +247,8 @@ def main():
             "metric": "frames/sec fwd+bwd (SemanticKITTI synth), whole job",
             "value": round(frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "bf16 ViT GEMM operands, f32 accumulate and everything else (configs[4] mode, not the reference precision)" if args.bf16_forward else "f32",
+            "data": "synthetic",
             "config": {"workload": "BASELINE configs[1] frame shape at configs[3] per-GPU batch: %s-shaped synthetic frames, %dx%d image, "
                                    "%d points/batch, %sFusionTransformer (DeiT-B/16-384 distilled + SPVCNN), fwd+loss+bwd+Adam, fp32, random-init weights"
                                    % (args.shape, SHAPES[args.shape]["H"], SHAPES[args.shape]["W"], n_points, args.kind.capitalize()),

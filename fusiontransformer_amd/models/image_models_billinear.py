@@ -117,6 +117,8 @@ class Net2DBillinear(nn.Module):
             new_state_dict = OrderedDict((k.replace("backbone.", ""), v) for k, v in ckpt.items() if "backbone" in k)
             self.backbone.load_state_dict(new_state_dict)
         self.backbone.set_attention_impl(kw.get("attn_impl", "ftx"))
+        if kw.get("vit_bf16", os.environ.get("FTX_VIT_BF16", "0") == "1"):
+            self.backbone.set_bf16(True)   # BASELINE configs[4] "bf16 forward"; default is fp32 like the reference
         # Training on the GPU runs the trunk as HIP graphs, one per tapped segment (transformers.py): ~500 kernel launches
         # per step become 4 graph launches, which takes 7 ms off the host side of a step (batch 4: the host issue time
         # drops from ~24 to ~17 ms, so the step stays GPU-bound on a slow host; +26-30 % frames/s at batch 1-2).

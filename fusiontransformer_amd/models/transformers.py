@@ -38,26 +38,34 @@ class _LinearFn(torch.autograd.Function):
     and the later replays of a captured backward, tools/probes/graph_block4.py)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, bf16=False):
         x2 = x.reshape(-1, x.shape[-1])
+        ctx.in_shape, ctx.bf16 = x.shape, bool(bf16)
+        if bf16:
+            # BASELINE configs[4] ("bf16 forward"): operands rounded to bf16, products accumulated in fp32 by the bf16 MFMA
+            # path, result and bias add in fp32; the two backward GEMMs run the same way, the bias gradient stays fp32
+            x2, w = x2.to(torch.bfloat16), w.to(torch.bfloat16)
+            ctx.save_for_backward(x2, w)
+            return (x2 @ w.t()).float().add_(b).view(*x.shape[:-1], w.shape[0])
         ctx.save_for_backward(x2, w)
-        ctx.in_shape = x.shape
         return torch.addmm(b, x2, w.t()).view(*x.shape[:-1], w.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         x2, w = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
-        dx = (dy2 @ w).view(ctx.in_shape) if ctx.needs_input_grad[0] else None
-        dw = dy2.t() @ x2 if ctx.needs_input_grad[1] else None
         db = (_ones_row(dy2.shape[0], dy2) @ dy2).view(-1) if ctx.needs_input_grad[2] else None
-        return dx, dw, db
+        if ctx.bf16:
+            dy2 = dy2.to(torch.bfloat16)
+        dx = (dy2 @ w).float().view(ctx.in_shape) if ctx.needs_input_grad[0] else None
+        dw = (dy2.t() @ x2).float() if ctx.needs_input_grad[1] else None
+        return dx, dw, db, None
 
 
 def _linear(x, lin):
     if lin.bias is None or not x.is_cuda:
         return F.linear(x, lin.weight, lin.bias)
-    return _LinearFn.apply(x, lin.weight, lin.bias)
+    return _LinearFn.apply(x, lin.weight, lin.bias, getattr(lin, "ftx_bf16", False))
 
 
 class Mlp(nn.Module):
@@ -166,6 +174,14 @@ class Image2DTransformer(nn.Module):
             elif isinstance(m, nn.LayerNorm):
                 nn.init.zeros_(m.bias)
                 nn.init.ones_(m.weight)
+
+    def set_bf16(self, on: bool = True):
+        """bf16 operands for the qkv / proj / MLP GEMMs of every block (fp32 accumulate, fp32 everywhere else: LayerNorm,
+        softmax, residual stream, attention kernel).  No counterpart in the reference, which is fp32 end to end; the parity
+        bar for this mode is stated in tests/test_model_gpu.py."""
+        for blk in self.blocks:
+            for lin in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2):
+                lin.ftx_bf16 = bool(on)
 
     def set_attention_impl(self, impl: str):
         for blk in self.blocks:

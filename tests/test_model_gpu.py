@@ -257,3 +257,28 @@ def test_deferred_index_build_equals_lazy_build():
         assert (ka.n_pairs, ka.n_in, ka.n_out) == (kb.n_pairs, kb.n_in, kb.n_out), key
         for f in ("nbr", "pos", "pos_t", "pair_in", "pair_out", "koff"):
             assert torch.equal(getattr(ka, f), getattr(kb, f)), (key, f)
+
+
+def test_bf16_forward_mode_stays_close_to_the_fp32_oracle():
+    """BASELINE configs[4] ("bf16 forward"): ViT GEMM operands in bf16.  The reference has no such mode (it is fp32 end
+    to end), so the bar is the fp32 oracle with a looser tolerance, stated here: per-point logits within 3e-2 (measured
+    ~5e-3 on this model; the fp32 path is held to 1e-3), and the LiDAR head -- which only sees the image through the
+    fused features -- within 2e-2."""
+    from fusiontransformer_amd.data.synth import make_batch
+    cfg, oracle, model, _ = _pair("middle", seed=1)
+    batch = make_batch([0, 1], max_points=2500)
+    oracle.eval(); model.eval()
+    model.image_backbone.backbone.set_bf16(True)
+    with torch.no_grad():
+        ref = oracle(oracle_inputs(batch))
+        out = model(product_inputs(batch))
+    err = {k: (out[k].cpu() - ref[k]).abs().max().item() for k in ref}
+    assert err["img_seg_logit"] <= 3e-2 and err["lidar_seg_logit"] <= 2e-2, err
+    assert err["img_seg_logit"] > 1e-6, "bf16 mode did not engage"
+    # and a training step runs with finite gradients
+    model.train()
+    from fusiontransformer_amd.trainer import fusion_losses
+    o = model(product_inputs(batch))
+    l2, l3 = fusion_losses(o, product_inputs(batch)["seg_label"], None, 0.1, True)
+    (l2 + l3).backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
