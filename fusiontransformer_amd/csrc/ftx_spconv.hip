@@ -322,6 +322,8 @@ static void launch_pairs_gemm(int nt, dim3 grid, hipStream_t st, const float *A,
   }
 }
 
+#include "ftx_spconv_dma.h"
+
 static int gemm_nt(int co) {
   int nt = co >= 128 ? 4 : (co + 31) / 32;
   if (co > 128 && co % 96 == 0 && co % 128 != 0) nt = 3;
@@ -336,6 +338,15 @@ static int gemm_rt(int64_t n_pairs, int kvol, int ca, int co) {
   return forced == 2 ? 2 : 1;
 }
 
+// The LDS-DMA kernel (ftx_spconv_dma.h) takes whole 32-channel chunks and whole column tiles; everything else (the
+// 4-channel stem, the class heads) stays on the register-staged kernel.  Measured on MI355X over the 20 layers of
+// tools/bench_spconv.py it ties the register-staged kernel (891 vs 903 us forward, 911 vs 893 us dgrad: 3-5 % faster on
+// the deep levels, 2-3 % slower on level 0), so it is an opt-in tuning alternative: FTX_GEMM_DMA=1.
+static bool gemm_use_dma(int64_t n_rows, int ca, int co, int nt) {
+  static const int enabled = getenv("FTX_GEMM_DMA") ? atoi(getenv("FTX_GEMM_DMA")) : 0;
+  return enabled && n_rows >= 1 && ca % 32 == 0 && co % (32 * nt) == 0;
+}
+
 extern "C" int ftx_spconv_pairs_gemm(const float *A, int64_t rows_a, const int32_t *gather, const float *W, int32_t w_transposed,
                                      const int32_t *koff, int64_t n_pairs, int32_t ca, int32_t co, int32_t kvol, float *tmp, void *stream) {
   FTX_REQUIRE(n_pairs >= 0 && rows_a >= 0 && kvol >= 1 && kvol <= 64, "ftx_spconv_pairs_gemm: bad size");
@@ -346,7 +357,10 @@ extern "C" int ftx_spconv_pairs_gemm(const float *A, int64_t rows_a, const int32
   const int nt = gemm_nt(co), rt = gemm_rt(n_pairs, kvol, ca, co);
   const unsigned tiles_ub = (unsigned)(ceil_div(n_pairs, TILE_P * rt) + kvol);  // sum_k ceil(cnt_k/tile) <= P/tile + kvol
   dim3 grid(tiles_ub, (unsigned)ceil_div(co, 32 * nt));
-  if (rt == 2)
+  if (rt == 1 && gemm_use_dma(n_pairs, ca, co, nt)) {
+    FTX_REQUIRE(dma::dispatch(nt, grid, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0) == 0,
+                "ftx_spconv_pairs_gemm: could not configure the LDS-DMA kernel");
+  } else if (rt == 2)
     launch_pairs_gemm<2>(nt, grid, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0);
   else
     launch_pairs_gemm<1>(nt, grid, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0);
@@ -365,7 +379,10 @@ extern "C" int ftx_rows_gemm(const float *A, int64_t n, const float *W, int32_t 
   hipStream_t st = (hipStream_t)stream;
   const int nt = gemm_nt(co), rt = gemm_rt(n, 1, ca, co);
   dim3 grid((unsigned)ceil_div(n, TILE_P * rt), (unsigned)ceil_div(co, 32 * nt));
-  if (rt == 2)
+  if (rt == 1 && gemm_use_dma(n, ca, co, nt)) {
+    FTX_REQUIRE(dma::dispatch(nt, grid, st, A, n, nullptr, W, w_transposed, nullptr, ca, co, 1, out, bias, n) == 0,
+                "ftx_rows_gemm: could not configure the LDS-DMA kernel");
+  } else if (rt == 2)
     launch_pairs_gemm<2>(nt, grid, st, A, n, nullptr, W, w_transposed, nullptr, ca, co, 1, out, bias, n);
   else
     launch_pairs_gemm<1>(nt, grid, st, A, n, nullptr, W, w_transposed, nullptr, ca, co, 1, out, bias, n);

@@ -1,5 +1,7 @@
 """Op-level parity of the libftx kernels against the CPU oracle (bit-exact for integer /
 index work, tight fp32 tolerances for feature movement and sparse conv)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -476,3 +478,46 @@ def test_batch_with_an_empty_frame_and_far_coordinates(env):
         nbr = km.nbr.cpu().numpy(); ci = cm.coords[cur].cpu().numpy(); co = ref_out
         kk, oo = np.nonzero(nbr >= 0)
         assert np.array_equal(ci[nbr[kk, oo], 3], co[oo, 3])
+
+
+def test_lds_dma_gemm_variant_matches_the_default_kernel(env):
+    """The opt-in LDS-DMA pair GEMM (FTX_GEMM_DMA=1, csrc/ftx_spconv_dma.h) against the default register-staged kernel:
+    same tiles, same MFMA order, so the results are bit-identical -- forward and transposed weights, full and ragged
+    tiles, dense rows with bias.  Run in a child process because the switch is read once per process."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys, torch
+        sys.path.insert(0, %r)
+        from fusiontransformer_amd import functional as spf
+        from fusiontransformer_amd.data.synth import make_batch
+        from fusiontransformer_amd.models.utils import initial_voxelize
+        from fusiontransformer_amd.sparse import PointTensor
+        torch.manual_seed(0)
+        b = make_batch([0, 1], max_points=6000)
+        z = PointTensor(torch.from_numpy(b["feats"]).cuda(), torch.from_numpy(b["coords"]).float().cuda())
+        cm = initial_voxelize(z, 1, 1).cm
+        L = spf._lib.load()
+        outs = []
+        for ks, s, st, ca, co in [(3, 1, 1, 32, 32), (3, 1, 1, 128, 96), (3, 1, 1, 64, 128), (2, 1, 2, 32, 64), (3, 2, 1, 96, 256)]:
+            km = cm.kernel_map(ks, s, st)
+            A = torch.randn(km.n_in, ca, device="cuda")
+            for wt in (0, 1):
+                W = torch.randn(ks ** 3, *((co, ca) if wt else (ca, co)), device="cuda") * 0.1
+                tmp = torch.zeros(km.n_pairs, co, device="cuda")
+                rc = L.ftx_spconv_pairs_gemm(A.data_ptr(), km.n_in, km.pair_in.data_ptr(), W.data_ptr(), wt, km.koff.data_ptr(), km.n_pairs, ca, co, ks ** 3, tmp.data_ptr(), spf.stream())
+                assert rc == 0
+                outs.append(tmp.cpu())
+        x = torch.randn(1000, 64, device="cuda"); w = torch.randn(96, 64, device="cuda"); bias = torch.randn(96, device="cuda")
+        outs.append(spf.linear(x, w, bias).cpu())
+        torch.save(outs, sys.argv[1])
+    """) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        for flag in ("0", "1"):
+            out = os.path.join(d, "o%s.pt" % flag)
+            subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, FTX_GEMM_DMA=flag), timeout=300)
+            res[flag] = torch.load(out, weights_only=True)
+    assert len(res["0"]) == len(res["1"]) == 11
+    for a, b in zip(res["0"], res["1"]):
+        assert torch.equal(a, b)

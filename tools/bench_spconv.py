@@ -40,7 +40,7 @@ for name, ks, cur, st, ca, co in layers:
     G = torch.randn(km.n_out, co, device="cuda")
     L = spf._lib.load()
     tmp = torch.empty(km.n_pairs, co, device="cuda"); out = torch.empty(km.n_out, co, device="cuda")
-    t_g = timeit(lambda: L.ftx_spconv_pairs_gemm(A.data_ptr(), km.n_in, km.pair_in.data_ptr(), W.data_ptr(), 0, km.koff.data_ptr(), km.n_pairs, ca, co, ks ** 3, tmp.data_ptr(), spf.stream()))
+    t_g = timeit(lambda: L.ftx_spconv_pairs_gemm(A.data_ptr(), km.n_in, km.pair_in.data_ptr(), W.data_ptr(), int(os.environ.get("FTX_BENCH_WT", "0")), km.koff.data_ptr(), km.n_pairs, ca, co, ks ** 3, tmp.data_ptr(), spf.stream()))
     t_r = timeit(lambda: L.ftx_spconv_reduce(tmp.data_ptr(), km.pos.data_ptr(), km.n_out, co, ks ** 3, out.data_ptr(), spf.stream()))
     t_w = timeit(lambda: spf._spconv_wgrad(A, km.pair_in, G, km.pair_out, km.koff, km.n_pairs))
     fl = 2.0 * km.n_pairs * ca * co
