@@ -239,6 +239,92 @@ __global__ __launch_bounds__(256) void kdma(float *out, const int *idx, const fl
       *(float4 *)&dst[j * 32 + 8 * q + 4 * half] = make_float4(acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
 }
 
+// wgrad-like tile stream with LDS-DMA: per step 32 pairs, A rows (128 ch) and G rows (32 NT ch) gathered by index into
+// unpadded images [32 pairs][channels]; dW tile (128 x 32 NT) accumulates over `iters` steps; fragments by ds_read_b32.
+template <int NT>
+__global__ __launch_bounds__(256) void kdma_wgrad(float *out, const int *idx_a, const int *idx_g, const float *rows_a, const float *rows_g, int iters) {
+  constexpr int TM = 128, TN = 32 * NT, A_BYTES = 32 * TM * 4, G_BYTES = 32 * TN * 4, STAGE = A_BYTES + G_BYTES;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // A image: 16 pieces of 1 KiB = 2 pairs x 512 B each; wave w issues pieces w*4 .. w*4+3 (pairs w*8 .. w*8+7)
+  // G image: TN*4*32/1024 = NT*4 pieces; wave w issues pieces w*NT .. (rows of TN*4 bytes, linear)
+  f32x16 acc[NT];
+  for (int j = 0; j < NT; ++j) for (int g = 0; g < 16; ++g) acc[j][g] = 0.f;
+  const size_t base = (size_t)blockIdx.x * iters * 32;
+  auto issue = [&](int it, int buf) {
+    const unsigned sa = lds0 + buf * STAGE;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int piece = wave * 4 + u;                       // 1 KiB = pairs 2*piece, 2*piece+1
+      const int pr = piece * 2 + (lane >> 5);
+      const int ia = idx_a[(base + (size_t)it * 32 + pr) & 0xFFFFF];
+      glds16(rows_a + (size_t)ia * TM + (lane & 31) * 4, sa + piece * 1024);
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const int e = (wave * NT + u) * 64 + lane;            // float4 index in the G image
+      const int pr = e / (TN / 4), c4 = (e % (TN / 4)) * 4;
+      const int ig = idx_g[(base + (size_t)it * 32 + pr) & 0xFFFFF];
+      glds16(rows_g + (size_t)ig * TN + c4, sa + A_BYTES + (wave * NT + u) * 1024);
+    }
+  };
+  issue(0, 0);
+  for (int it = 0; it < iters; ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (it + 1 < iters) issue(it + 1, (it + 1) & 1);
+    const float *as = (const float *)(smem + (it & 1) * STAGE), *gs = (const float *)(smem + (it & 1) * STAGE + A_BYTES);
+#pragma unroll
+    for (int kk2 = 0; kk2 < 16; ++kk2) {
+      const int kk = 2 * kk2 + half;
+      float a = as[kk * TM + wave * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float b = gs[kk * TN + j * 32 + l31];
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  float *dst = out + ((size_t)blockIdx.x * 128 + wave * 32 + l31) * TN;
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *(float4 *)&dst[j * 32 + 8 * q + 4 * half] = make_float4(acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
+}
+
+template <int NT>
+void run_wgrad(const char *name, int grid, int iters, int n_rows) {
+  constexpr int TM = 128, TN = 32 * NT;
+  float *out, *ra, *rg; int *ia, *ig;
+  (void)hipMalloc(&out, sizeof(float) * (size_t)grid * 128 * TN);
+  (void)hipMalloc(&ra, sizeof(float) * (size_t)n_rows * TM); (void)hipMalloc(&rg, sizeof(float) * (size_t)n_rows * TN);
+  (void)hipMalloc(&ia, sizeof(int) * (1 << 20)); (void)hipMalloc(&ig, sizeof(int) * (1 << 20));
+  std::vector<int> h(1 << 20), h2(1 << 20); unsigned x = 777u;
+  for (size_t i = 0; i < h.size(); ++i) { x = x * 1664525u + 1013904223u; h[i] = (int)((x >> 8) % (unsigned)n_rows); h2[i] = (int)((i / 5) % (unsigned)n_rows); }
+  (void)hipMemcpy(ia, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice);
+  (void)hipMemcpy(ig, h2.data(), sizeof(int) * h2.size(), hipMemcpyHostToDevice);
+  std::vector<float> hr((size_t)n_rows * TM);
+  for (auto &v : hr) { x = x * 1664525u + 1013904223u; v = (x >> 9) / 8388608.0f - 1.0f; }
+  (void)hipMemcpy(ra, hr.data(), sizeof(float) * hr.size(), hipMemcpyHostToDevice);
+  (void)hipMemcpy(rg, hr.data(), sizeof(float) * (size_t)n_rows * TN, hipMemcpyHostToDevice);
+  const int lds = 2 * (32 * TM * 4 + 32 * TN * 4);
+  (void)hipFuncSetAttribute((const void *)kdma_wgrad<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  kdma_wgrad<NT><<<grid, 256, lds>>>(out, ia, ig, ra, rg, iters);
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0);
+  for (int r = 0; r < 20; ++r) kdma_wgrad<NT><<<grid, 256, lds>>>(out, ia, ig, ra, rg, iters);
+  (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 20;
+  double flops = (double)grid * 4 * iters * 16 * NT * 4096.0;
+  printf("%-58s NT=%d grid=%d steps/block=%d  %.1f us  %.1f TFLOP/s\n", name, NT, grid, iters, ms * 1e3, flops / ms / 1e9);
+  (void)hipFree(out); (void)hipFree(ra); (void)hipFree(rg); (void)hipFree(ia); (void)hipFree(ig);
+}
+
 template <int NT>
 void run_gather(const char *name, int grid, int iters, int n_rows, bool random_data, int dma_bufs = 0) {
   const int ca = iters * 32;
@@ -331,5 +417,8 @@ int main() {
   run_gather<3>("LDS-DMA tile, 3 buffers (81k rows, random data)", 3017, 4, 81237, true, 3);
   run_gather<4>("LDS-DMA tile NT=4, 2 buffers (81k rows, random)", 2990, 4, 81237, true, 2);
   run_gather<3>("LDS-DMA tile 12 steps, 2 buffers (20k rows, random)", 1000, 12, 20197, true, 2);
+  run_wgrad<3>("wgrad-like LDS-DMA: 1536 blocks x 8 steps (128x96 tile)", 1536, 8, 81237);
+  run_wgrad<3>("wgrad-like LDS-DMA: 768 blocks x 16 steps", 768, 16, 81237);
+  run_wgrad<4>("wgrad-like LDS-DMA: 1536 blocks x 8 steps (128x128 tile)", 1536, 8, 81237);
   return 0;
 }
