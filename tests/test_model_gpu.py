@@ -282,3 +282,26 @@ def test_bf16_forward_mode_stays_close_to_the_fp32_oracle():
     l2, l3 = fusion_losses(o, product_inputs(batch)["seg_label"], None, 0.1, True)
     (l2 + l3).backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+def test_refused_graph_capture_falls_back_to_eager(monkeypatch, capsys):
+    """If HIP-graph capture of the trunk is refused (e.g. another thread touches the device while the stream is being
+    captured), training goes on eagerly instead of failing."""
+    from fusiontransformer_amd.data.synth import make_batch
+    from fusiontransformer_amd.trainer import fusion_losses
+
+    def refuse(*a, **k):
+        raise RuntimeError("operation not permitted when stream is capturing")
+
+    monkeypatch.setattr(torch.cuda, "make_graphed_callables", refuse)
+    cfg, oracle, model, _ = _pair("middle", seed=6)
+    model.train()
+    pin = product_inputs(make_batch([4], max_points=2000))
+    for _ in range(2):
+        out = model(pin)
+        l2, l3 = fusion_losses(out, pin["seg_label"], None, 0.1, True)
+        (l2 + l3).backward()
+    torch.cuda.synchronize()
+    assert all(v is None for v in model.image_backbone.backbone._graph_cache.values())
+    assert "running it eagerly" in capsys.readouterr().err
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
