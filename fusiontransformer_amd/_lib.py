@@ -56,13 +56,10 @@ SIGNATURES = {
     "ftx_spconv_pairs_gemm": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "ftx_rows_gemm": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "ftx_spconv_reduce": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
-    "ftx_spconv_reduce_stats": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
     "ftx_spconv_pairs_wgrad_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "ftx_spconv_pairs_wgrad": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "ftx_bn_workspace_bytes": (_sz, [_i64, _i32]),
     "ftx_bn_train_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "ftx_bn_partial_blocks": (C.c_int32, [_i64]),
-    "ftx_bn_train_fwd_from_partials": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ftx_bn_eval_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i32, _i32, _vp, _vp]),
     "ftx_attn_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     "ftx_attn_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32]),

@@ -180,30 +180,6 @@ extern "C" int ftx_bn_train_fwd(const float *x, const float *residual, const flo
   return check_launch("ftx_bn_train_fwd");
 }
 
-// Forward from partial sums that somebody else produced in bn_partial_kernel<FwdOp>'s layout (the sparse-conv reduce pass
-// does, see ftx_spconv_reduce_stats): finalize + apply only, one pass over x less.
-extern "C" int32_t ftx_bn_partial_blocks(int64_t n) { return bn_blocks(n); }
-
-extern "C" int ftx_bn_train_fwd_from_partials(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean,
-                                              float *running_var, float momentum, float eps, int64_t n, int32_t c, int32_t relu, float *y,
-                                              float *save_mean, float *save_invstd, const void *partials, size_t partials_bytes, void *stream) {
-  int rc = bn_check("ftx_bn_train_fwd_from_partials", n, c);
-  if (rc != FTX_OK) return rc;
-  FTX_REQUIRE(n >= 1, "ftx_bn_train_fwd_from_partials: needs at least one row");
-  FTX_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && partials, "ftx_bn_train_fwd_from_partials: null pointer");
-  FTX_REQUIRE(c <= 512, "ftx_bn_train_fwd_from_partials: c > 512 unsupported");
-  const int nb = bn_blocks(n);
-  if (partials_bytes < sizeof(double) * (size_t)nb * 2 * c) {
-    set_error("ftx_bn_train_fwd_from_partials: partials %zu < required %zu", partials_bytes, sizeof(double) * (size_t)nb * 2 * c);
-    return FTX_EWORKSPACE;
-  }
-  hipStream_t st = (hipStream_t)stream;
-  bn_finalize_fwd_kernel<<<ceil_div(c, 4), 256, 0, st>>>((const double *)partials, nb, n, c, eps, momentum, running_mean, running_var, save_mean,
-                                                         save_invstd);
-  bn_apply_fwd_kernel<<<grid_for(n * (c / 4), 256), 256, 0, st>>>(x, residual, gamma, beta, save_mean, save_invstd, n, c, relu, y);
-  return check_launch("ftx_bn_train_fwd_from_partials");
-}
-
 __global__ void bn_apply_eval_kernel(const float *__restrict__ x, const float *__restrict__ res, const float *__restrict__ gamma,
                                      const float *__restrict__ beta, const float *__restrict__ rm, const float *__restrict__ rv, float eps,
                                      int64_t n, int c, int relu, float *__restrict__ y) {

@@ -442,90 +442,6 @@ extern "C" int ftx_spconv_reduce(const float *tmp, const int32_t *pos, int64_t n
   return check_launch("ftx_spconv_reduce");
 }
 
-// Reduce pass that also produces the BatchNorm statistics of its output: per-block partial column sums of out and
-// out^2 in float64, in exactly the layout and row partition of bn_partial_kernel<FwdOp> (ftx_bn.hip) -- block b owns a
-// contiguous range of rows, thread (rl, cg) walks rows r0 + rl, + RL, ... of channel group cg -- so the statistics are
-// bit-identical to the separate pass they replace (one read of `out` and one launch less per convolution).
-extern "C" int32_t ftx_bn_partial_blocks(int64_t n);
-
-template <int KVOL>
-__global__ __launch_bounds__(256) void spconv_reduce_stats_kernel(const float *__restrict__ tmp, const int32_t *__restrict__ pos, int64_t n, int co,
-                                                                  int kvol, float *__restrict__ out, double *__restrict__ part) {
-  extern __shared__ double sh[];  // [2][RL][co]
-  const int c4 = co >> 2;
-  const int RL = 256 / c4 > 0 ? 256 / c4 : 1;
-  const int tid = threadIdx.x;
-  const int cg = tid % c4, rl = tid / c4;
-  const int64_t rows_per_block = ceil_div(n, (int64_t)gridDim.x);
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-  const int64_t r1 = (r0 + rows_per_block < n) ? r0 + rows_per_block : n;
-  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
-  if (rl < RL) {
-    for (int64_t r = r0 + rl; r < r1; r += RL) {
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (KVOL > 0) {
-        int32_t p[KVOL > 0 ? KVOL : 1];
-#pragma unroll
-        for (int k = 0; k < KVOL; ++k) p[k] = pos[(int64_t)k * n + r];
-#pragma unroll
-        for (int k = 0; k < KVOL; ++k) {
-          if (p[k] >= 0) {
-            float4 v = *(const float4 *)&tmp[(int64_t)p[k] * co + cg * 4];
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-          }
-        }
-      } else {
-        for (int k = 0; k < kvol; ++k) {
-          int32_t q = pos[(int64_t)k * n + r];
-          if (q >= 0) {
-            float4 v = *(const float4 *)&tmp[(int64_t)q * co + cg * 4];
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-          }
-        }
-      }
-      *(float4 *)&out[r * co + cg * 4] = acc;
-      s0[0] += (double)acc.x; s1[0] += (double)acc.x * (double)acc.x;
-      s0[1] += (double)acc.y; s1[1] += (double)acc.y * (double)acc.y;
-      s0[2] += (double)acc.z; s1[2] += (double)acc.z * (double)acc.z;
-      s0[3] += (double)acc.w; s1[3] += (double)acc.w * (double)acc.w;
-    }
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      sh[(0 * RL + rl) * co + cg * 4 + v] = s0[v];
-      sh[(1 * RL + rl) * co + cg * 4 + v] = s1[v];
-    }
-  }
-  __syncthreads();
-  for (int j = tid; j < 2 * co; j += 256) {
-    int which = j / co, col = j - which * co;
-    double s = 0;
-    for (int q = 0; q < RL; ++q) s += sh[(which * RL + q) * co + col];
-    part[((int64_t)blockIdx.x * 2 + which) * co + col] = s;
-  }
-}
-
-extern "C" int ftx_spconv_reduce_stats(const float *tmp, const int32_t *pos, int64_t n, int32_t co, int32_t kvol, float *out, void *partials,
-                                       size_t partials_bytes, void *stream) {
-  FTX_REQUIRE(n >= 1 && kvol >= 1 && co >= 4 && co % 4 == 0 && co <= 512, "ftx_spconv_reduce_stats: bad size");
-  FTX_REQUIRE(pos && out && partials, "ftx_spconv_reduce_stats: null pointer");
-  const int nb = ftx_bn_partial_blocks(n);
-  if (partials_bytes < sizeof(double) * (size_t)nb * 2 * co) {
-    set_error("ftx_spconv_reduce_stats: partials %zu < required %zu", partials_bytes, sizeof(double) * (size_t)nb * 2 * co);
-    return FTX_EWORKSPACE;
-  }
-  const int c4 = co / 4;
-  const int RL = 256 / c4 > 0 ? 256 / c4 : 1;
-  const size_t lds = sizeof(double) * 2 * RL * co;
-  hipStream_t st = (hipStream_t)stream;
-  if (kvol == 27)
-    spconv_reduce_stats_kernel<27><<<nb, 256, lds, st>>>(tmp, pos, n, co, kvol, out, (double *)partials);
-  else if (kvol == 8)
-    spconv_reduce_stats_kernel<8><<<nb, 256, lds, st>>>(tmp, pos, n, co, kvol, out, (double *)partials);
-  else
-    spconv_reduce_stats_kernel<0><<<nb, 256, lds, st>>>(tmp, pos, n, co, kvol, out, (double *)partials);
-  return check_launch("ftx_spconv_reduce_stats");
-}
-
 // ---------------------------------------------------------------------------------------
 // weight gradient: dW[k] = sum_{p in k} A[idx_a[p],:]^T @ G[idx_g[p],:]
 // Block (tile of one offset's pairs, mt, nt) reduces its pairs into a (32 WM) x (32 NT) tile of dW[k];

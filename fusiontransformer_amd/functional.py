@@ -381,79 +381,6 @@ class _SparseConv(torch.autograd.Function):
         return g_feats, g_kernel, None, None
 
 
-class _SparseConvBN(torch.autograd.Function):
-    """Training-mode Conv3d -> BatchNorm(+residual)(+ReLU) as ONE autograd node: pair GEMM, a reduce pass that also
-    leaves the BatchNorm partial sums behind (`ftx_spconv_reduce_stats`), finalize + apply.  Same arithmetic, bit for
-    bit, as sparse_conv followed by batch_norm; one launch, one pass over the conv output and one Python node less per
-    layer in each direction."""
-
-    @staticmethod
-    def forward(ctx, feats, kernel, gamma, beta, residual, km, transposed, running_mean, running_var, momentum, eps, relu):
-        L = _lib.load()
-        feats = req(feats.contiguous(), F32, "conv3d feats", 2)
-        kernel = req(kernel.contiguous(), F32, "conv3d kernel", 3)
-        kvol, ca, co = kernel.shape
-        n_in, n_out = (km.n_out, km.n_in) if transposed else (km.n_in, km.n_out)
-        if feats.shape != (n_in, ca) or km.kvol != kvol:
-            raise ValueError(f"conv3d: shape mismatch feats {tuple(feats.shape)} kernel {tuple(kernel.shape)} map ({km.kvol},{n_in}->{n_out})")
-        for t, nm in ((gamma, "gamma"), (beta, "beta")):
-            req(t, F32, "bn " + nm, 1)
-            if t.shape[0] != co:
-                raise ValueError("bn: parameter length != channels")
-        if residual is not None:
-            residual = req(residual.contiguous(), F32, "bn residual", 2)
-            if tuple(residual.shape) != (n_out, co):
-                raise ValueError("bn: residual shape mismatch")
-        gather, pos = (km.pair_out, km.pos_t) if transposed else (km.pair_in, km.pos)
-        n_pairs = km.n_pairs
-        tmp = _empty((n_pairs, co), F32, feats)
-        x = _empty((n_out, co), F32, feats)
-        y = _empty((n_out, co), F32, feats)
-        stats = _empty((2, co), F32, feats)          # save_mean, save_invstd
-        part_bytes = 8 * int(L.ftx_bn_partial_blocks(n_out)) * 2 * co
-        part = torch.empty((part_bytes,), dtype=torch.uint8, device=feats.device)
-        meta = dict(pairs=n_pairs, n_out=n_out, ca=ca, co=co, kvol=kvol)
-        _log_launch("spconv_pairs_gemm", meta, lambda: check(L.ftx_spconv_pairs_gemm(
-            ptr(feats), n_in, ptr(gather), ptr(kernel), 0, ptr(km.koff), n_pairs, ca, co, kvol, ptr(tmp), stream()), "ftx_spconv_pairs_gemm"))
-        _log_launch("spconv_reduce", meta, lambda: check(L.ftx_spconv_reduce_stats(
-            ptr(tmp), ptr(pos), n_out, co, kvol, ptr(x), ptr(part), part_bytes, stream()), "ftx_spconv_reduce_stats"))
-        check(L.ftx_bn_train_fwd_from_partials(ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum),
-                                               float(eps), n_out, co, int(relu), ptr(y), ptr(stats[0]), ptr(stats[1]), ptr(part), part_bytes, stream()),
-              "ftx_bn_train_fwd_from_partials")
-        ctx.save_for_backward(feats, kernel, x, y, gamma, stats)
-        ctx.km, ctx.transposed, ctx.relu, ctx.has_res = km, transposed, int(relu), residual is not None
-        return y
-
-    @staticmethod
-    def backward(ctx, gy):
-        L = _lib.load()
-        feats, kernel, x, y, gamma, stats = ctx.saved_tensors
-        km, transposed = ctx.km, ctx.transposed
-        gy = req(gy.contiguous(), F32, "bn grad", 2)
-        n, co = x.shape
-        kvol, ca, _ = kernel.shape
-        gx = torch.empty_like(x)
-        gres = torch.empty_like(x) if ctx.has_res else None
-        gpar = _empty((2, co), F32, x)               # grad_gamma, grad_beta
-        ws_bytes = int(L.ftx_bn_workspace_bytes(n, co))
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
-        check(L.ftx_bn_train_bwd(ptr(gy), ptr(x), ptr(y), ptr(gamma), ptr(stats[0]), ptr(stats[1]), n, co, ctx.relu, ptr(gx), ptr(gres), ptr(gpar[0]),
-                                 ptr(gpar[1]), ptr(ws), ws_bytes, stream()), "ftx_bn_train_bwd")
-        g_feats = g_kernel = None
-        in_side, out_side = (km.pair_out, km.pair_in) if transposed else (km.pair_in, km.pair_out)
-        if ctx.needs_input_grad[0]:
-            pos_in = km.pos if transposed else km.pos_t
-            g_feats = _spconv_apply(gx, kernel, out_side, pos_in, km.koff, km.n_pairs, feats.shape[0], ca, 1)
-        if ctx.needs_input_grad[1]:
-            g_kernel = _spconv_wgrad(feats, in_side, gx, out_side, km.koff, km.n_pairs)
-        return g_feats, g_kernel, gpar[0], gpar[1], gres, None, None, None, None, None, None, None
-
-
-def sparse_conv_bn(feats, kernel, km, transposed, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, residual=None, relu=False):
-    """Training-mode sparse conv + BatchNorm (+ residual) (+ ReLU) in one node (see _SparseConvBN)."""
-    return _SparseConvBN.apply(feats, kernel, gamma, beta, residual, km, transposed, running_mean, running_var, momentum, eps, relu)
-
-
 def sparse_conv(feats, kernel, km, transposed=False):
     return _SparseConv.apply(feats, kernel, km, transposed)
 

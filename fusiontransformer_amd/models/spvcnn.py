@@ -87,25 +87,6 @@ class ReLU(nn.ReLU):
 
 
 def _conv_bn(conv, bn, x, residual=None, relu=True):
-    if conv.k > 1 and bn.training and x.F.is_cuda and conv.out_channels <= 512 and os.environ.get("FTX_FUSED_CONV_BN", "1") != "0":
-        # one node: pair GEMM, reduce + BatchNorm statistics in one pass, finalize + apply (functional._SparseConvBN)
-        ks, s = conv.kernel_size, conv.stride
-        if not conv.t:
-            km = x.cm.kernel_map(ks, x.s, s)
-            coords, stride = km.out_coords, x.s * s
-        else:
-            stride = x.s // s
-            km = x.cm.kernel_maps.get((ks, stride, s))
-            if km is None:
-                raise RuntimeError("transposed Conv3d needs the kernel map of the paired strided Conv3d")
-            coords = x.cm.coords[stride]
-        if bn.track_running_stats and bn.num_batches_tracked is not None and not getattr(bn, "_nbt_external", False):
-            bn.num_batches_tracked.add_(1)
-        feats = spf.sparse_conv_bn(x.F, conv.kernel, km, conv.t, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
-                                   residual=residual, relu=relu)
-        out = x.derive(feats, coords, stride)
-        out.check()
-        return out
     y = conv(x)
     return y.derive(bn.fused(y.F, residual=residual, relu=relu))
 

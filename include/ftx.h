@@ -173,10 +173,6 @@ int ftx_rows_gemm(const float *A, int64_t n, const float *W, int32_t w_transpose
 
 /* out[r,:] = sum over k (ascending) of tmp[pos[k,r],:] for pos >= 0; out (n, co) fully written. */
 int ftx_spconv_reduce(const float *tmp, const int32_t *pos, int64_t n, int32_t co, int32_t kvol, float *out, void *stream);
-/* The same reduce that also leaves the BatchNorm statistics of `out` behind: per-block float64 partial sums of out
- * and out^2 in the layout ftx_bn_train_fwd's own statistics pass uses (ftx_bn_partial_blocks(n) blocks x 2 x co doubles,
- * partials_bytes >= that), to be consumed by ftx_bn_train_fwd_from_partials.  n >= 1, co <= 512. */
-int ftx_spconv_reduce_stats(const float *tmp, const int32_t *pos, int64_t n, int32_t co, int32_t kvol, float *out, void *partials, size_t partials_bytes, void *stream);
 
 /* dW[k] = sum_{p in offset k} A[idx_a[p],:]^T @ G[idx_g[p],:]  -> dW (kvol, ca, cg), fully written.
  * idx_a = idx_g = koff = NULL with kvol = 1: dense rows, dW = A[:n_pairs]^T @ G[:n_pairs]. */
@@ -193,10 +189,6 @@ int ftx_spconv_pairs_wgrad(const float *A, int64_t rows_a, const int32_t *idx_a,
  * running_mean / running_var may be NULL (no update).  residual may be NULL. */
 size_t ftx_bn_workspace_bytes(int64_t n, int32_t c);
 int ftx_bn_train_fwd(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean, float *running_var, float momentum, float eps, int64_t n, int32_t c, int32_t relu, float *y, float *save_mean, float *save_invstd, void *workspace, size_t workspace_bytes, void *stream);
-/* ftx_bn_train_fwd without its statistics pass: `partials` were produced by ftx_spconv_reduce_stats over the same x
- * (n rows, c channels).  Same outputs, bit for bit. */
-int32_t ftx_bn_partial_blocks(int64_t n);
-int ftx_bn_train_fwd_from_partials(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean, float *running_var, float momentum, float eps, int64_t n, int32_t c, int32_t relu, float *y, float *save_mean, float *save_invstd, const void *partials, size_t partials_bytes, void *stream);
 /* Eval forward with running statistics. */
 int ftx_bn_eval_fwd(const float *x, const float *residual, const float *gamma, const float *beta, const float *running_mean, const float *running_var, float eps, int64_t n, int32_t c, int32_t relu, float *y, void *stream);
 /* Training backward.  y is the forward output (needed for the ReLU mask when relu!=0).

@@ -305,29 +305,3 @@ def test_refused_graph_capture_falls_back_to_eager(monkeypatch, capsys):
     assert all(v is None for v in model.image_backbone.backbone._graph_cache.values())
     assert "running it eagerly" in capsys.readouterr().err
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
-
-
-def test_fused_conv_bn_node_is_bit_identical_to_the_separate_ops(monkeypatch):
-    """Conv3d -> BatchNorm -> ReLU as one autograd node (statistics produced by the conv's reduce pass) against the
-    separate sparse_conv / batch_norm nodes: logits, gradients and running statistics, bit for bit."""
-    from fusiontransformer_amd.data.synth import make_batch
-    from fusiontransformer_amd.trainer import fusion_losses
-    pin = product_inputs(make_batch([1, 5], max_points=3000))
-
-    def run(flag):
-        monkeypatch.setenv("FTX_FUSED_CONV_BN", flag)
-        cfg, oracle, model, _ = _pair("middle", seed=7)
-        model.train()
-        torch.manual_seed(0)
-        out = model(pin)
-        l2, l3 = fusion_losses(out, pin["seg_label"], None, 0.1, True)
-        (l2 + l3).backward()
-        torch.cuda.synchronize()
-        return ({k: v.detach().clone() for k, v in out.items()}, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None},
-                {n: b.clone() for n, b in model.named_buffers()})
-
-    a, b = run("0"), run("1")
-    for part_a, part_b in zip(a, b):
-        assert part_a.keys() == part_b.keys()
-        for k in part_a:
-            assert torch.equal(part_a[k], part_b[k]), k
