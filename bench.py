@@ -159,6 +159,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bf16-forward", action="store_true",
                     help="BASELINE configs[4]: ViT GEMMs with bf16 operands (fp32 accumulate); NOT the headline configuration, the line says so in dtype")
+    ap.add_argument("--no-nuscenes", action="store_true", help="skip the secondary measurement on NuScenes-shaped frames (BASELINE configs[2])")
     ap.add_argument("--no-batch1", action="store_true", help="skip the secondary measurement at batch 1 (the literal BASELINE configs[1] frame)")
     ap.add_argument("--serial-branches", action="store_true",
                     help="issue the image and LiDAR branches back to back on one stream in every step (profiling aid: under rocprofv3 "
@@ -271,6 +272,30 @@ def main():
             ms1 = 1e3 * (time.perf_counter() - t1) / 10
             out["config"]["batch1_configs1_literal"] = {"frames_per_sec": round(1e3 / ms1, 2), "ms_per_step": round(ms1, 3), "steps": 10,
                                                        "points": int(one["lidar"].F.shape[0])}
+        if world == 1 and args.shape != "nuscenes" and not args.no_nuscenes and not args.bf16_forward:
+            # secondary figure, outside the timed region: BASELINE configs[2], NuScenes-shaped frames (900x1600 image, ~27 k points
+            # per frame) at the same per-GPU batch, through a second model built for that lift size
+            del step, model
+            torch.cuda.empty_cache()
+            cfg_n = fusion_cfg(args.kind)
+            cfg_n.MODEL.attn_impl = args.attn
+            cfg_n.MODEL.lift_size = (SHAPES["nuscenes"]["H"], SHAPES["nuscenes"]["W"])
+            torch.manual_seed(0)
+            model_n, m2n, m3n = build_model(cfg_n)
+            model_n = model_n.to(device).train()
+            step_n = TrainStep(cfg_n, model_n, metrics=(m2n, m3n))
+            nb, data_n = build_inputs(cfg_n, args.batch, "nuscenes", rank, device)
+            for _ in range(3):
+                step_n(data_n)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                step_n(data_n)
+            torch.cuda.synchronize()
+            msn = 1e3 * (time.perf_counter() - t1) / 10
+            out["config"]["nuscenes_shaped_configs2"] = {"frames_per_sec": round(args.batch * 1e3 / msn, 2), "ms_per_step": round(msn, 3), "steps": 10,
+                                                        "frames_per_gpu": args.batch, "points": int(nb["coords"].shape[0]),
+                                                        "image": "%dx%d" % (SHAPES["nuscenes"]["H"], SHAPES["nuscenes"]["W"])}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, np_batch)
         print(json.dumps(out), flush=True)
