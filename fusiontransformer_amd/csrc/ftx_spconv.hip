@@ -676,11 +676,12 @@ static void wgrad_config(int ca, int cg, int *wm, int *nt) {
   *nt = n;
 }
 
-// pairs per tile: aim at ~6 blocks per CU over all (tile, M-tile, N-tile) blocks, 128..4096 pairs
+// pairs per tile: aim at ~4 blocks per CU over all (tile, M-tile, N-tile) blocks, 128..4096 pairs (measured over the 20
+// layers of tools/bench_spconv.py: 768 / 1024 / 1280 / 1536 / 2048 blocks -> 1336 / 1275 / 1316 / 1304 / 1360 us)
 static int wgrad_tile_len(int64_t n_pairs, int ca, int cg, int kvol) {
   int wm, nt;
   wgrad_config(ca, cg, &wm, &nt);
-  static const int target = getenv("FTX_WGRAD_BLOCKS") ? atoi(getenv("FTX_WGRAD_BLOCKS")) : 1536;
+  static const int target = getenv("FTX_WGRAD_BLOCKS") ? atoi(getenv("FTX_WGRAD_BLOCKS")) : 1024;
   int64_t mn_tiles = ceil_div(ca, 32 * wm) * ceil_div(cg, 32 * nt);
   int64_t want_tiles = ceil_div(target, mn_tiles);
   int64_t len = ceil_div(ceil_div(n_pairs, want_tiles), WG_BR) * WG_BR;
