@@ -31,11 +31,13 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 T
 MFMA_F32_PEAK_TFLOPS = 157.3  # exact-fp32 MFMA peak (same guide)
 
 
-def build_inputs(cfg, batch, shape, rank, device):
+def build_inputs(cfg, batch, shape, rank, device, cycle=0):
+    """One resident batch.  `cycle` selects a different set of frames (seeds), so the timed loop can alternate between
+    DISTINCT batches: every per-batch structure (voxel hash, kernel maps, sorted segments) is rebuilt in every step."""
     from fusiontransformer_amd.data.synth import make_batch
     from fusiontransformer_amd.models.image_models_billinear import pack_img_indices
     from fusiontransformer_amd.sparse import SparseTensor
-    b = make_batch([rank * batch + i for i in range(batch)], shape=shape)
+    b = make_batch([1000 * cycle + rank * batch + i for i in range(batch)], shape=shape)
     data = {
         "img": torch.from_numpy(b["img"]).to(device),
         "img_indices": pack_img_indices(b["img_indices"], device),
@@ -153,6 +155,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4, help="frames per GPU per step")
+    ap.add_argument("--cycle", type=int, default=2, help="distinct resident batches the steps alternate between (>= 2: nothing per-batch can be cached across steps)")
     ap.add_argument("--shape", default="kitti", choices=["kitti", "nuscenes"])
     ap.add_argument("--kind", default="middle", choices=["middle", "early", "late"])
     ap.add_argument("--attn", default=os.environ.get("FTX_ATTN", "ftx"), choices=["ftx", "torch"])
@@ -186,14 +189,11 @@ def main():
     device = torch.device("cuda", local_rank)
 
     if args.tune_gemm:
-        # The ViT's dense GEMMs are plain library calls (hipBLASLt / rocBLAS through torch).  TunableOp
-        # times the available solutions for each of the ~20 shapes during the warm-up steps and keeps
-        # the fastest (hipBLASLt's default heuristic picks a 26 TFLOP/s kernel for the 2312x768x768
-        # projection; the tuned choice runs at ~90).  Tuning happens before the timed region.
-        import torch.cuda.tunable as tunable
-        tunable.enable(True)
-        tunable.tuning_enable(True)
-        tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "ftx_tunableop_rank%d.csv" % rank))
+        # The ViT's dense GEMMs are plain library calls (hipBLASLt / rocBLAS through torch); TunableOp keeps the fastest
+        # solution per shape.  The results are read from the file committed next to libftx.so, so a job tunes once
+        # (fusiontransformer_amd/gemm_tuning.py); shapes missing from it are tuned during the warm-up steps, before the timed region.
+        from fusiontransformer_amd import gemm_tuning
+        gemm_tuning.enable(rank)
 
     cfg = fusion_cfg(args.kind)
     cfg.MODEL.attn_impl = args.attn
@@ -205,8 +205,11 @@ def main():
         model.image_backbone.backbone.set_bf16(True)
     reducer = GradReducer(model) if world > 1 else None
     step = TrainStep(cfg, model, metrics=(m2d, m3d), grad_reducer=reducer)
-    np_batch, data = build_inputs(cfg, args.batch, args.shape, rank, device)
-    n_points = int(np_batch["coords"].shape[0])
+    batches = [build_inputs(cfg, args.batch, args.shape, rank, device, cycle=c) for c in range(max(1, args.cycle))]
+    np_batch = batches[0][0]
+    datas = [d for _, d in batches]
+    points = [int(b["coords"].shape[0]) for b, _ in batches]
+    n_points = points[0]
 
     def barrier():
         if world > 1:
@@ -214,9 +217,9 @@ def main():
         torch.cuda.synchronize()
 
     if rank == 0:
-        log("model and %d-point batch resident; warm-up" % n_points)
-    for _ in range(args.warmup):
-        step(data)
+        log("model and %d resident batches (%s points) resident; warm-up" % (len(datas), points))
+    for i in range(args.warmup):
+        step(datas[i % len(datas)])
     barrier()
     if rank == 0:
         log("timing %d steps" % args.steps)
@@ -230,7 +233,7 @@ def main():
             # the kernels' own and not inflated by the ViT GEMMs running beside them.
             launch_log = spf.LAUNCH_LOG = []
             model.overlap_branches = False
-        step(data)
+        step(datas[i % len(datas)])
     spf.LAUNCH_LOG = None
     model.overlap_branches = not args.serial_branches
     barrier()
@@ -254,6 +257,7 @@ def main():
                                    "%d points/batch, %sFusionTransformer (DeiT-B/16-384 distilled + SPVCNN), fwd+loss+bwd+Adam, fp32, random-init weights"
                                    % (args.shape, SHAPES[args.shape]["H"], SHAPES[args.shape]["W"], n_points, args.kind.capitalize()),
                        "frames_per_gpu": args.batch, "global_batch": args.batch * world, "points_per_gpu_batch": n_points,
+                       "resident_batches_cycled": len(datas), "points_of_each_resident_batch": points,
                        "attention": args.attn, "library_gemm_tuning": bool(args.tune_gemm), "branch_overlap": "off (--serial-branches)" if args.serial_branches else "2 HIP streams (image / LiDAR)",
                        "parallelism": "dp%d" % world},
             "frames_per_sec_per_gpu": round(frames / elapsed / world, 3),
@@ -261,13 +265,14 @@ def main():
         }
         if world == 1 and args.batch != 1 and not args.no_batch1:
             # secondary figure, outside the timed region above: the literal BASELINE configs[1] workload (ONE frame per step)
-            _, one = build_inputs(cfg, 1, args.shape, rank, device)
-            for _ in range(3):
-                step(one)
+            ones = [build_inputs(cfg, 1, args.shape, rank, device, cycle=c)[1] for c in range(max(1, args.cycle))]
+            one = ones[0]
+            for i in range(4):
+                step(ones[i % len(ones)])
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(10):
-                step(one)
+            for i in range(10):
+                step(ones[i % len(ones)])
             torch.cuda.synchronize()
             ms1 = 1e3 * (time.perf_counter() - t1) / 10
             out["config"]["batch1_configs1_literal"] = {"frames_per_sec": round(1e3 / ms1, 2), "ms_per_step": round(ms1, 3), "steps": 10,
@@ -284,13 +289,14 @@ def main():
             model_n, m2n, m3n = build_model(cfg_n)
             model_n = model_n.to(device).train()
             step_n = TrainStep(cfg_n, model_n, metrics=(m2n, m3n))
-            nb, data_n = build_inputs(cfg_n, args.batch, "nuscenes", rank, device)
-            for _ in range(3):
-                step_n(data_n)
+            nbs = [build_inputs(cfg_n, args.batch, "nuscenes", rank, device, cycle=c) for c in range(max(1, args.cycle))]
+            nb = nbs[0][0]
+            for i in range(4):
+                step_n(nbs[i % len(nbs)][1])
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(10):
-                step_n(data_n)
+            for i in range(10):
+                step_n(nbs[i % len(nbs)][1])
             torch.cuda.synchronize()
             msn = 1e3 * (time.perf_counter() - t1) / 10
             out["config"]["nuscenes_shaped_configs2"] = {"frames_per_sec": round(args.batch * 1e3 / msn, 2), "ms_per_step": round(msn, 3), "steps": 10,
@@ -299,6 +305,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, np_batch)
         print(json.dumps(out), flush=True)
+    if args.tune_gemm and rank == 0:
+        from fusiontransformer_amd import gemm_tuning
+        if gemm_tuning.save(rank):
+            log("library-GEMM selections written to %s" % gemm_tuning.SHARED)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -106,7 +106,7 @@ def run_fusion(model, data_dict, lidar_steps, overlap=True):
     if model.training:
         bump_batchnorm_counters(model)
     if not (overlap and img.is_cuda):
-        preds_image = model.image_backbone(img=img, img_indices=data_dict["img_indices"], on_middle=lazy.set)
+        preds_image = model.image_backbone(img=img, img_indices=data_dict["img_indices"], on_middle=lazy.set, lift_size=data_dict.get("lift_size"))
         return _drain(lidar_steps(lazy)), preds_image
     cur = torch.cuda.current_stream()
     s_img, s_lid = _branch_streams(img.device)
@@ -133,7 +133,8 @@ def run_fusion(model, data_dict, lidar_steps, overlap=True):
             state["blocked"] = True
 
     with torch.cuda.stream(s_img):
-        preds_image = model.image_backbone(img=img, img_indices=data_dict["img_indices"], on_middle=lazy.set, on_step=pump)
+        preds_image = model.image_backbone(img=img, img_indices=data_dict["img_indices"], on_middle=lazy.set, on_step=pump,
+                                           lift_size=data_dict.get("lift_size"))
     while not state["done"]:
         if state["blocked"] and lazy.feats is None:
             raise RuntimeError("the LiDAR branch needs image features the image branch never produced")

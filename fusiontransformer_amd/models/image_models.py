@@ -13,5 +13,5 @@ class ImageSegBilinear(nn.Module):
         self.image_backbone = Net2DBillinear(num_classes=num_classes, dual_head=dual_head, backbone_2d_kwargs=backbone_2d_kwargs)
 
     def forward(self, data_dict):
-        preds_image = self.image_backbone(data_dict["img"], data_dict["img_indices"])
+        preds_image = self.image_backbone(data_dict["img"], data_dict["img_indices"], lift_size=data_dict.get("lift_size"))
         return {"img_seg_logit": preds_image["img_seg_logit"]}

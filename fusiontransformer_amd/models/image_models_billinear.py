@@ -50,6 +50,8 @@ class BilinearModule(nn.Module):
             nn.Conv2d(in_channels=in_features, out_channels=out_features, kernel_size=1),
             nn.ReLU(True),
             nn.BatchNorm2d(out_features))
+        if isinstance(interpolation_output_size, str):     # "image": per-batch lift size, resolved in Net2DBillinear
+            interpolation_output_size = (370, 1226)        # the reference literal (image_models_billinear.py:74,77)
         self.up = nn.Upsample(interpolation_output_size)   # kept for parity of the module tree; executed by libftx
         self.size = tuple(interpolation_output_size)
 
@@ -92,7 +94,8 @@ class Net2DBillinear(nn.Module):
         self.hidden_channels = 768   # ViT width
         # the reference hard-codes (370, 1226) (image_models_billinear.py:74,77); other
         # lift sizes (384x1248, 900x1600) are throughput-only shapes
-        self.lift_size = tuple(kw.get("lift_size", (370, 1226)))
+        ls = kw.get("lift_size", (370, 1226))
+        self.lift_size = ls if isinstance(ls, str) else tuple(ls)
 
         self.sample_down = BilinearModule(in_features=3, out_features=3, interpolation_output_size=(384, 384))
 
@@ -149,28 +152,52 @@ class Net2DBillinear(nn.Module):
         if dual_head:
             self.linear2 = nn.Linear(self.feat_channels, num_classes)
 
-    def get_img_feats(self, img_indices, block_id: str, image_shape: tuple, backbone_output: Dict):
-        """reference image_models_billinear.py:88-126 -> (sum N, 96)."""
+    def _lift_hw(self, image_shape, lift_size=None):
+        """Size of the (never materialised) up-sampled map.  The reference hard-codes (370, 1226)
+        (image_models_billinear.py:74,77) and ignores `image_shape` (:101); `lift_size="image"` in the
+        config or a per-batch `lift_size` in the data dict selects the batch's own image size instead, so one
+        model serves KITTI- and NuScenes-shaped batches (BASELINE configs[4])."""
+        if lift_size is None:
+            lift_size = self.lift_size
+        if isinstance(lift_size, str):
+            if lift_size != "image":
+                raise ValueError("lift_size must be (H, W) or 'image'")
+            lift_size = tuple(int(v) for v in image_shape[-2:])
+        h, w = int(lift_size[0]), int(lift_size[1])
+        if h <= 0 or w <= 0:
+            raise ValueError("lift_size must be positive")
+        return h, w
+
+    def get_img_feats(self, img_indices, block_id: str, image_shape: tuple, backbone_output: Dict, lift_ctx=None, lift_size=None):
+        """reference image_models_billinear.py:88-126 -> (sum N, 96).
+
+        `lift_ctx` is a dict that lives for ONE forward: the taps of that forward share the sort of the points by
+        source cell (the lift's atomic-free backward) through it.  Nothing about a batch is kept on the module."""
         x = backbone_output[block_id]
         g = 384 // 16
         grid = self.up[block_id].forward_tokens(x, (g, g))
         idx, frame = pack_img_indices(img_indices, x.device)
+        H, W = self._lift_hw(image_shape, lift_size)
         seg = None
         if torch.is_grad_enabled() and grid.requires_grad:
-            key = (idx.data_ptr(), frame.data_ptr(), grid.shape[0], g, self.lift_size)
-            cache = getattr(self, "_lift_seg", None)
-            if cache is None or cache[0] != key:       # both taps of a forward share one sort
-                cache = (key, spf.lift_segments(idx, frame, grid.shape[0], g, g, self.lift_size[0], self.lift_size[1]))
-                object.__setattr__(self, "_lift_seg", cache)
-            seg = cache[1]
-        return spf.lift_gather(grid, idx, frame, self.lift_size[0], self.lift_size[1], seg)
+            key = ("seg", grid.shape[0], g, H, W)
+            if lift_ctx is None:
+                lift_ctx = {}
+            # the cached entry holds the very tensors it was built from: `is` identity, never addresses
+            hit = lift_ctx.get(key)
+            if hit is None or hit[0] is not idx or hit[1] is not frame:
+                hit = (idx, frame, spf.lift_segments(idx, frame, grid.shape[0], g, g, H, W))
+                lift_ctx[key] = hit
+            seg = hit[2]
+        return spf.lift_gather(grid, idx, frame, H, W, seg)
 
-    def forward(self, img, img_indices, on_middle=None, on_step=None):
+    def forward(self, img, img_indices, on_middle=None, on_step=None, lift_size=None):
         """reference image_models_billinear.py:128-155.  `on_middle(feats)` is called with the lifted
         features of the middle tap as soon as that block has run (the LiDAR branch, on another
         stream, only waits for this and not for the rest of the ViT); `on_step()` after every issued
         chunk of work (the scheduler uses it to interleave the other branch's kernel launches)."""
         img_indices = pack_img_indices(img_indices, img.device)
+        lift_ctx = {}     # per-forward: both taps share one sort of the points by source cell
         x = self.sample_down(img)
         if on_step is not None:
             on_step()
@@ -178,14 +205,15 @@ class Net2DBillinear(nn.Module):
 
         def tap(i, tokens):
             if self.middle_feat_block_number is not None and str(i) == self.middle_feat_block_number and self.middle_feat_block_number in self.up:
-                middle["feats"] = self.get_img_feats(img_indices, self.middle_feat_block_number, img.shape, {self.middle_feat_block_number: tokens})
+                middle["feats"] = self.get_img_feats(img_indices, self.middle_feat_block_number, img.shape, {self.middle_feat_block_number: tokens},
+                                                        lift_ctx=lift_ctx, lift_size=lift_size)
                 if on_middle is not None:
                     on_middle(middle["feats"])
             if on_step is not None:
                 on_step()
 
         backbone_output = self.backbone.forward_blocks(x, on_block=tap)
-        late_feats = self.get_img_feats(img_indices, self.late_feat_block_number, img.shape, backbone_output)
+        late_feats = self.get_img_feats(img_indices, self.late_feat_block_number, img.shape, backbone_output, lift_ctx=lift_ctx, lift_size=lift_size)
         x = spf.linear(late_feats, self.linear.weight, self.linear.bias)
         preds = {"img_feats": late_feats, "img_seg_logit": x}
         if self.dual_head:

@@ -214,6 +214,11 @@ class Image2DTransformer(nn.Module):
                     if on_block is not None:
                         on_block(last, outputs[str(last)])
             return outputs
+        if x.is_cuda and self.training and torch.is_grad_enabled():
+            # This pass and its backward run eagerly.  A capture attempted AFTER an eager backward through these parameters
+            # aborts the process inside hipStreamEndCapture on torch 2.10 / ROCm 7 (tools/probes/graph_recapture.py) -- an abort,
+            # not an exception -- so from here on no NEW capture is attempted (already captured shapes keep replaying).
+            self.__dict__["_graph_capture_off"] = True
         x = self._embed(x)
         outputs = dict()
         for i, block in enumerate(self.blocks):
@@ -232,19 +237,31 @@ class Image2DTransformer(nn.Module):
     graph_taps = None   # sorted block indices whose outputs the caller uses; None: eager execution
     graph_segment_blocks = 3
 
+    def _graph_key(self, x):
+        """Everything a captured graph bakes in: input shape / dtype / requires_grad, the tap set and segment length, the
+        per-block execution flags and the parameters' requires_grad pattern.  Changing any of them selects another graph."""
+        flags = tuple((blk.attn.attn_impl, bool(getattr(blk.attn.qkv, "ftx_bf16", False)), bool(getattr(blk.mlp.fc1, "ftx_bf16", False)))
+                      for blk in self.blocks)
+        grads = tuple(p.requires_grad for p in self.parameters())
+        return (tuple(x.shape), x.dtype, bool(x.requires_grad), tuple(self.graph_taps), self.last_block, self.graph_segment_blocks,
+                flags, grads, torch.cuda.current_device())
+
     def _graphed_segments(self, x):
         if not self.graph_taps or not x.is_cuda or not self.training or not torch.is_grad_enabled():
             return None
         cache = self.__dict__.setdefault("_graph_cache", {})
-        key = (tuple(x.shape), x.dtype, tuple(self.graph_taps), torch.cuda.current_device())
+        key = self._graph_key(x)
         if key not in cache:
+            if self.__dict__.get("_graph_capture_off", False):
+                return None      # an eager training pass or a refused capture came before: never capture again (see forward_blocks)
             try:
                 cache[key] = self._capture_segments(x)
             except Exception as err:   # capture refused (another thread touched the device, unsupported op, ...): run eagerly
                 import sys
-                print("[fusiontransformer_amd] HIP-graph capture of the ViT trunk failed (%s: %s); running it eagerly" % (type(err).__name__, err),
+                print("[fusiontransformer_amd] HIP-graph capture of the ViT trunk failed (%s: %s); running it eagerly from now on" % (type(err).__name__, err),
                       file=sys.stderr, flush=True)
                 cache[key] = None
+                self.__dict__["_graph_capture_off"] = True
         return cache[key]
 
     def _capture_segments(self, x):

@@ -40,7 +40,11 @@ def test_build_model_dispatch_and_state_dict_names(kind, cls):
         assert prefix + k in names, k
     for k in ("image_backbone.backbone.blocks.0.attn.qkv.weight", "image_backbone.sample_down.stem.0.weight", "image_backbone.linear.weight"):
         assert k in names, k
-    assert sd[prefix + "stage1.0.net.0.kernel"].shape == (8, 32, 32) and sd[prefix + "stage1.1.downsample.0.kernel"].shape == (32, 32) if False else True
+    # strided 2^3 conv: (8, inc, inc); the residual shortcut exists only where the channel count changes (spvcnn.py:66-72)
+    assert sd[prefix + "stage1.0.net.0.kernel"].shape == (8, 32, 32)
+    assert prefix + "stage1.1.downsample.0.kernel" not in names
+    assert sd[prefix + "stage2.1.downsample.0.kernel"].shape == (32, 64)
+    assert sd[prefix + "up1.1.0.net.0.kernel"].shape == (27, 256 + 128, 256)
     # parameters that never get a gradient are frozen (DDP without find_unused_parameters)
     assert not any(p.requires_grad for p in model.image_backbone.backbone.norm.parameters())
 

@@ -305,3 +305,41 @@ def test_refused_graph_capture_falls_back_to_eager(monkeypatch, capsys):
     assert all(v is None for v in model.image_backbone.backbone._graph_cache.values())
     assert "running it eagerly" in capsys.readouterr().err
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    # The trunk's parameters have now been through EAGER backwards: capturing after that aborts the process inside
+    # hipStreamEndCapture (tools/probes/README.md).  A new batch shape must therefore NOT trigger another capture attempt.
+    calls = []
+    monkeypatch.setattr(torch.cuda, "make_graphed_callables", lambda *a, **k: calls.append(1) or refuse())
+    pin2 = product_inputs(make_batch([4, 5], max_points=1500))        # batch 2 instead of 1: another graph key
+    out = model(pin2)
+    l2, l3 = fusion_losses(out, pin2["seg_label"], None, 0.1, True)
+    (l2 + l3).backward()
+    torch.cuda.synchronize()
+    assert calls == [], "a capture was attempted after an eager training pass of the trunk"
+
+
+def test_eager_training_pass_switches_later_captures_off():
+    """graphs on, but the first training passes run eagerly (graph_taps toggled by the caller): once any eager training pass has
+    gone through the trunk, turning graphs back on must not capture (it would abort in hipStreamEndCapture)."""
+    from fusiontransformer_amd.data.synth import make_batch
+    from fusiontransformer_amd.trainer import fusion_losses
+    cfg, oracle, model, _ = _pair("middle", seed=7)
+    model.train()
+    trunk = model.image_backbone.backbone
+    taps = trunk.graph_taps
+    assert taps
+    pin = product_inputs(make_batch([1], max_points=1500))
+    # a training forward under no_grad (e.g. a BN re-estimation pass) is harmless and must not switch captures off
+    with torch.no_grad():
+        model(pin)
+    assert not trunk.__dict__.get("_graph_capture_off", False)
+    trunk.graph_taps = None
+    out = model(pin)
+    l2, l3 = fusion_losses(out, pin["seg_label"], None, 0.1, True)
+    (l2 + l3).backward()                       # eager backward through the trunk
+    assert trunk.__dict__.get("_graph_capture_off", False)
+    trunk.graph_taps = taps                    # the caller turns graphs back on: must replay nothing and capture nothing
+    out = model(pin)
+    l2, l3 = fusion_losses(out, pin["seg_label"], None, 0.1, True)
+    (l2 + l3).backward()
+    torch.cuda.synchronize()
+    assert not trunk.__dict__.get("_graph_cache"), "captured although captures were switched off"
