@@ -69,7 +69,7 @@ def test_full_size_nuscenes_shaped_frame():
     from fusiontransformer_amd.data.synth import SHAPES, make_batch
     hw = (SHAPES["nuscenes"]["H"], SHAPES["nuscenes"]["W"])
     cfg, oracle, model = _full_pair("middle", lift_size=hw, seed=1)
-    batch = make_batch([3], shape="nuscenes")
+    batch = make_batch([2], shape="nuscenes")
     assert batch["coords"].shape[0] > 22000 and batch["img"].shape[-2:] == hw
     with torch.no_grad():
         ref = oracle(oracle_inputs(batch))
