@@ -54,6 +54,7 @@ SIGNATURES = {
     "ftx_sample_down_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "ftx_sample_down_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ftx_spconv_pairs_gemm": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "ftx_spconv_pairs_gemm_scatter": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "ftx_rows_gemm": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "ftx_spconv_reduce": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "ftx_spconv_pairs_wgrad_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),

@@ -134,8 +134,10 @@ template <int NT, int RT>
 __global__ __launch_bounds__(256) void pairs_gemm_kernel(const float *__restrict__ A, int64_t rows_a, const int32_t *__restrict__ gather,
                                                          const float *__restrict__ W, int w_transposed, const int32_t *__restrict__ koff,
                                                          int ca, int co, int kvol, float *__restrict__ tmp, const float *__restrict__ bias,
-                                                         int64_t n_dense) {
+                                                         int64_t n_dense, const int32_t *__restrict__ scatter, int64_t rows_out) {
   // gather == nullptr: dense mode, tmp[r,:] = A[r,:] @ W (+ bias) for r < n_dense (kvol = 1)
+  // scatter != nullptr: the result row of pair p goes to row scatter[p] of `tmp` (rows_out rows) instead of row p: for maps in
+  // which every destination row receives exactly ONE pair the convolution is this one launch, with no tmp and no reduce pass
   constexpr int TILE = TILE_P * RT;
   constexpr int BN = 32 * NT;
   constexpr int BS_STRIDE = AS_STRIDE;         // W chunk kept as Bs[n][k]: the reduction index is contiguous for BOTH operands
@@ -291,8 +293,13 @@ __global__ __launch_bounds__(256) void pairs_gemm_kernel(const float *__restrict
 #pragma unroll
   for (int r = 0; r < RT; ++r) {
     const int row = wave * 32 * RT + r * 32 + l31;
-    if (row < cnt) {
-      float *dst = tmp + (int64_t)(p0 + row) * co;
+    int64_t drow = row < cnt ? p0 + row : -1;
+    if (scatter != nullptr && drow >= 0) {
+      drow = scatter[drow];
+      if (drow >= rows_out) drow = -1;
+    }
+    if (drow >= 0) {
+      float *dst = tmp + drow * co;
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -313,12 +320,13 @@ __global__ __launch_bounds__(256) void pairs_gemm_kernel(const float *__restrict
 
 template <int RT>
 static void launch_pairs_gemm(int nt, dim3 grid, hipStream_t st, const float *A, int64_t rows_a, const int32_t *gather, const float *W, int wT,
-                              const int32_t *koff, int ca, int co, int kvol, float *tmp, const float *bias, int64_t n_dense) {
+                              const int32_t *koff, int ca, int co, int kvol, float *tmp, const float *bias, int64_t n_dense,
+                              const int32_t *scatter = nullptr, int64_t rows_out = 0) {
   switch (nt) {
-    case 1: pairs_gemm_kernel<1, RT><<<grid, 256, 0, st>>>(A, rows_a, gather, W, wT, koff, ca, co, kvol, tmp, bias, n_dense); break;
-    case 2: pairs_gemm_kernel<2, RT><<<grid, 256, 0, st>>>(A, rows_a, gather, W, wT, koff, ca, co, kvol, tmp, bias, n_dense); break;
-    case 3: pairs_gemm_kernel<3, RT><<<grid, 256, 0, st>>>(A, rows_a, gather, W, wT, koff, ca, co, kvol, tmp, bias, n_dense); break;
-    default: pairs_gemm_kernel<4, RT><<<grid, 256, 0, st>>>(A, rows_a, gather, W, wT, koff, ca, co, kvol, tmp, bias, n_dense); break;
+    case 1: pairs_gemm_kernel<1, RT><<<grid, 256, 0, st>>>(A, rows_a, gather, W, wT, koff, ca, co, kvol, tmp, bias, n_dense, scatter, rows_out); break;
+    case 2: pairs_gemm_kernel<2, RT><<<grid, 256, 0, st>>>(A, rows_a, gather, W, wT, koff, ca, co, kvol, tmp, bias, n_dense, scatter, rows_out); break;
+    case 3: pairs_gemm_kernel<3, RT><<<grid, 256, 0, st>>>(A, rows_a, gather, W, wT, koff, ca, co, kvol, tmp, bias, n_dense, scatter, rows_out); break;
+    default: pairs_gemm_kernel<4, RT><<<grid, 256, 0, st>>>(A, rows_a, gather, W, wT, koff, ca, co, kvol, tmp, bias, n_dense, scatter, rows_out); break;
   }
 }
 
@@ -365,6 +373,24 @@ extern "C" int ftx_spconv_pairs_gemm(const float *A, int64_t rows_a, const int32
   else
     launch_pairs_gemm<1>(nt, grid, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0);
   return check_launch("ftx_spconv_pairs_gemm");
+}
+
+// One-launch convolution for maps whose destination side is a bijection of the pair list: out[scatter[p],:] = A[gather[p],:] @ Wk(p).
+// The strided 2^3 convolution joins every fine voxel to exactly one (coarse voxel, offset), so its data gradient and the
+// transposed convolution built on the same map (models/spvcnn.py:38-50) write every fine row exactly once: no tmp, no reduce.
+// The caller guarantees that `scatter` is injective (rows it does not name are left untouched).
+extern "C" int ftx_spconv_pairs_gemm_scatter(const float *A, int64_t rows_a, const int32_t *gather, const int32_t *scatter, const float *W,
+                                             int32_t w_transposed, const int32_t *koff, int64_t n_pairs, int32_t ca, int32_t co, int32_t kvol,
+                                             float *out, int64_t rows_out, void *stream) {
+  FTX_REQUIRE(n_pairs >= 0 && rows_a >= 0 && rows_out >= 0 && kvol >= 1 && kvol <= 64, "ftx_spconv_pairs_gemm_scatter: bad size");
+  FTX_REQUIRE(ca >= 4 && ca % 4 == 0 && co >= 4 && co % 4 == 0, "ftx_spconv_pairs_gemm_scatter: channels must be multiples of 4 (ca=%d co=%d)", ca, co);
+  if (n_pairs == 0) return FTX_OK;
+  FTX_REQUIRE(A && gather && scatter && W && koff && out, "ftx_spconv_pairs_gemm_scatter: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int nt = gemm_nt(co);
+  dim3 grid((unsigned)(ceil_div(n_pairs, TILE_P) + kvol), (unsigned)ceil_div(co, 32 * nt));
+  launch_pairs_gemm<1>(nt, grid, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, out, nullptr, 0, scatter, rows_out);
+  return check_launch("ftx_spconv_pairs_gemm_scatter");
 }
 
 // Dense rows: out[r,:] = A[r,:] @ W (+ bias) on the same tile code (identity gather, one "offset").
@@ -444,36 +470,48 @@ extern "C" int ftx_spconv_reduce(const float *tmp, const int32_t *pos, int64_t n
 
 // ---------------------------------------------------------------------------------------
 // weight gradient: dW[k] = sum_{p in k} A[idx_a[p],:]^T @ G[idx_g[p],:]
-// Block (tile of one offset's pairs, mt, nt) reduces its pairs into a (32 WM) x (32 NT) tile of dW[k];
-// the tiles of an offset are combined by a second, ordered pass.
+//
+// Block = (tile of `tile_len` consecutive pairs of ONE offset, M tile, N tile) -> one (TM x TN) partial of dW[k]; the partials of
+// an offset are summed by an ordered second pass (an offset that fits one tile is written straight into dW[k]).
+//
+// The reduction index is the PAIR, so the gathered rows are staged row-major ([pair][channel], 16-byte stores) and used as they
+// are: a wave's (32 MI) x (32 NI) piece of the tile takes channels  base + MI*i + mi  /  base + NI*j + ni  for MFMA index i / j,
+// i.e. the MI (NI) sub-tiles interleave.  One lane then needs MI (NI) CONSECUTIVE floats of a staged row per reduction step: a
+// single ds_read_b64 / b128 per operand feeds MI*NI MFMAs (the previous kernel fed every MFMA from its own ds_read_b32), and the
+// accumulator registers of a lane hold 4*NI consecutive g-channels of MI a-channel rows, so the epilogue is 16-byte stores.
+// Waves: WMG x WNG x KS = 4; KS > 1 splits the pairs of each step and sums the KS groups through LDS in a fixed order.
 // ---------------------------------------------------------------------------------------
-constexpr int WG_BR = 32;      // pairs staged per step
+constexpr int WG_BR = 32;       // pairs staged per step
 constexpr int WG_ROUND = 1024;  // pair indices kept in LDS at a time
 
-// Tile = 32*WM channels of A (M) x 32*NT channels of G (N).  With WM < 4 the spare waves split
-// the pairs of each step (KS = 4/WM ways) and are summed through LDS at the end, so narrow
-// layers (32/64 channels, the levels with the most pairs) still keep all four SIMDs busy.
-template <int WM, int NT>
+template <int N> struct FragLoad;
+template <> struct FragLoad<1> { static __device__ __forceinline__ void ld(const float *p, float (&f)[1]) { f[0] = *p; } };
+template <> struct FragLoad<2> { static __device__ __forceinline__ void ld(const float *p, float (&f)[2]) { float2 v = *(const float2 *)p; f[0] = v.x; f[1] = v.y; } };
+template <> struct FragLoad<3> { static __device__ __forceinline__ void ld(const float *p, float (&f)[3]) { f[0] = p[0]; f[1] = p[1]; f[2] = p[2]; } };
+template <> struct FragLoad<4> { static __device__ __forceinline__ void ld(const float *p, float (&f)[4]) { float4 v = *(const float4 *)p; f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; } };
+
+template <int MI, int NI, int WMG, int WNG>
 __global__ __launch_bounds__(256) void pairs_wgrad_kernel(const float *__restrict__ A, int64_t rows_a, const int32_t *__restrict__ idx_a,
                                                           const float *__restrict__ G, int64_t rows_g, const int32_t *__restrict__ idx_g,
                                                           const int32_t *__restrict__ koff, int ca, int cg, int kvol, int tile_len,
-                                                          float *__restrict__ part, int n_dense) {
+                                                          float *__restrict__ part, float *__restrict__ dW, int n_dense) {
   // idx_a == nullptr: dense mode, rows [0, n_dense) of A and G pair up one to one (kvol = 1)
-  constexpr int TM = 32 * WM, TN = 32 * NT, KS = 4 / WM;
-  constexpr int ASTR = TM + 4, GSTR = TN + 4;
-  constexpr int RED = KS > 1 ? WM * NT * 1024 : 1;
-  __shared__ __attribute__((aligned(16))) float As[WG_BR * ASTR];
-  __shared__ __attribute__((aligned(16))) float Gs[WG_BR * GSTR];
-  __shared__ float red[RED];
+  constexpr int TM = 32 * MI * WMG, TN = 32 * NI * WNG, KS = 4 / (WMG * WNG);
+  constexpr int STAGE = WG_BR * (TM + TN);                 // floats
+  constexpr int RED = KS > 1 ? MI * NI * 1024 * WMG * WNG : 0;  // floats: one KS group's accumulators
+  constexpr int LDSF = STAGE > RED ? STAGE : RED;
+  __shared__ __attribute__((aligned(16))) float lds[LDSF];
   __shared__ int32_t s_ia[WG_ROUND], s_ig[WG_ROUND];
+  __shared__ int s_tile[4];
+  float *As = lds, *Gs = lds + WG_BR * TM;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int half = lane >> 5, l31 = lane & 31;
-  const int wm = wave % WM, ks = wave / WM;
-  // Tile = `tile_len` consecutive pairs of ONE offset.  Offsets differ a lot in pair count (the
-  // centre offset of a submanifold map has one pair per voxel, ~7x the others), so tiles are cut
-  // from the pair list, not per offset: a wave-level scan of koff maps block -> (offset, range).
-  __shared__ int s_tile[3];
+  const int wq = wave % (WMG * WNG), ks = wave / (WMG * WNG);
+  const int wm = wq % WMG, wn = wq / WMG;
+  // Tile = `tile_len` consecutive pairs of ONE offset.  Offsets differ a lot in pair count (the centre offset of a submanifold
+  // map has one pair per voxel, ~7x the others), so tiles are cut from the pair list, not per offset: a wave-level scan of
+  // koff maps block -> (offset, range).
   if (tid < 64) {
     const int b = blockIdx.x;
     int c = 0;
@@ -495,6 +533,7 @@ __global__ __launch_bounds__(256) void pairs_wgrad_kernel(const float *__restric
       s_tile[0] = tid;
       s_tile[1] = first;
       s_tile[2] = first + (left > tile_len ? tile_len : left);
+      s_tile[3] = nt;
     }
     if (msk == 0ull && tid == 0) s_tile[0] = -1;
   }
@@ -503,22 +542,24 @@ __global__ __launch_bounds__(256) void pairs_wgrad_kernel(const float *__restric
   if (k < 0) return;  // surplus block of the upper-bound grid
   const int m0 = blockIdx.y * TM, n0 = blockIdx.z * TN;
   const int lo = s_tile[1], hi = s_tile[2];
+  const bool single = s_tile[3] == 1;   // the only tile of its offset: the result IS dW[k]
 
-  f32x16 acc[NT];
+  f32x16 acc[MI][NI];
 #pragma unroll
-  for (int j = 0; j < NT; ++j)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int g = 0; g < 16; ++g) acc[j][g] = 0.f;
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
-  // Two register stages: the gathers of step s+2 are issued while step s is in the matrix cores, so
-  // a block hides its own load latency (blocks of one CU start together and stay in lockstep, so
-  // relying on the other resident blocks to cover it does not work).
-  float4 ra0[WM], rg0[NT], ra1[WM], rg1[NT];
-  int rbase = lo;  // first pair of the round whose indices are in LDS
-  int rend = lo;
-  auto load_step = [&](int p0, float4 (&ra)[WM], float4 (&rg)[NT]) {
+  // Two register stages: the gathers of step s+2 are issued while step s is in the matrix cores, so a block hides its own load
+  // latency (blocks of one CU start together and stay in lockstep, so relying on the other resident blocks does not work).
+  constexpr int QA = TM / 32, QG = TN / 32;   // float4 per thread per step and operand
+  float4 ra0[QA], rg0[QG], ra1[QA], rg1[QG];
+  int rbase = lo, rend = lo;
+  auto load_step = [&](int p0, float4 (&ra)[QA], float4 (&rg)[QG]) {
 #pragma unroll
-    for (int q = 0; q < WM; ++q) {
+    for (int q = 0; q < QA; ++q) {
       int e = q * 256 + tid;
       int pr = e / (TM / 4), c4 = (e - pr * (TM / 4)) * 4;
       int p = p0 + pr;
@@ -530,7 +571,7 @@ __global__ __launch_bounds__(256) void pairs_wgrad_kernel(const float *__restric
       ra[q] = v;
     }
 #pragma unroll
-    for (int q = 0; q < NT; ++q) {
+    for (int q = 0; q < QG; ++q) {
       int e = q * 256 + tid;
       int pr = e / (TN / 4), c4 = (e - pr * (TN / 4)) * 4;
       int p = p0 + pr;
@@ -542,30 +583,30 @@ __global__ __launch_bounds__(256) void pairs_wgrad_kernel(const float *__restric
       rg[q] = v;
     }
   };
-  auto store_step = [&](const float4 (&ra)[WM], const float4 (&rg)[NT]) {
+  auto store_step = [&](const float4 (&ra)[QA], const float4 (&rg)[QG]) {
 #pragma unroll
-    for (int q = 0; q < WM; ++q) {
-      int e = q * 256 + tid;
-      int pr = e / (TM / 4), c4 = (e - pr * (TM / 4)) * 4;
-      *(float4 *)&As[pr * ASTR + c4] = ra[q];
-    }
+    for (int q = 0; q < QA; ++q) *(float4 *)&As[(q * 256 + tid) * 4] = ra[q];   // row-major [pair][TM]: e*4 == pr*TM + c4
 #pragma unroll
-    for (int q = 0; q < NT; ++q) {
-      int e = q * 256 + tid;
-      int pr = e / (TN / 4), c4 = (e - pr * (TN / 4)) * 4;
-      *(float4 *)&Gs[pr * GSTR + c4] = rg[q];
-    }
+    for (int q = 0; q < QG; ++q) *(float4 *)&Gs[(q * 256 + tid) * 4] = rg[q];
   };
+  const float *ap = As + wm * 32 * MI + MI * l31, *gp = Gs + wn * 32 * NI + NI * l31;
   auto mfma_step = [&]() {
+    constexpr int ITS = WG_BR / 2 / KS;
+    float af[2][MI], gf[2][NI];
+    auto frag = [&](int buf, int it) {
+      const int kk = 2 * (it * KS + ks) + half;
+      FragLoad<MI>::ld(ap + kk * TM, af[buf]);
+      FragLoad<NI>::ld(gp + kk * TN, gf[buf]);
+    };
+    frag(0, 0);
 #pragma unroll
-    for (int it = 0; it < WG_BR / 2 / KS; ++it) {
-      int kk = 2 * (it * KS + ks) + half;
-      float a = As[kk * ASTR + wm * 32 + l31];
+    for (int it = 0; it < ITS; ++it) {
+      if (it + 1 < ITS) frag((it + 1) & 1, it + 1);   // next fragments in flight under this step's MFMAs
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        float b = Gs[kk * GSTR + j * 32 + l31];
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc[j], 0, 0, 0);  // G rows: accumulator = (g-channel, a-channel)
-      }
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(gf[it & 1][j], af[it & 1][i], acc[i][j], 0, 0, 0);  // rows: g-channel, cols: a-channel
     }
   };
 
@@ -596,43 +637,59 @@ __global__ __launch_bounds__(256) void pairs_wgrad_kernel(const float *__restric
     }
   }
 
-  if (KS > 1) {  // sum the pair-subsets of the KS wave groups, fixed order
+  if (KS > 1) {  // sum the pair-subsets of the KS wave groups, fixed order (the staging buffers are free now)
+    float *red = lds;
     for (int r = 1; r < KS; ++r) {
       if (ks == r) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int g = 0; g < 16; ++g) red[((wm * NT + j) * 16 + g) * 64 + lane] = acc[j][g];
+          for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) red[(((wq * MI + i) * NI + j) * 16 + g) * 64 + lane] = acc[i][j][g];
       }
       __syncthreads();
       if (ks == 0) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int g = 0; g < 16; ++g) acc[j][g] += red[((wm * NT + j) * 16 + g) * 64 + lane];
+          for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[i][j][g] += red[(((wq * MI + i) * NI + j) * 16 + g) * 64 + lane];
       }
       __syncthreads();
     }
   }
 
   if (ks == 0) {
-    float *dst = part + (int64_t)blockIdx.x * ca * cg;   // one partial per tile, tiles are numbered in offset order
-    // lane (a-channel l31, half) holds 4 consecutive g-channels in every 4 consecutive registers: 16-byte stores
-    const int row = m0 + wm * 32 + l31;
-    if (row < ca) {
+    const int64_t mat = (int64_t)ca * cg;
+    float *dst = single ? dW + (int64_t)k * mat : part + (int64_t)blockIdx.x * mat;   // tiles are numbered in offset order
+    // accumulator register 4q + e of lane (l31, half) is g-row 8q + 4*half + e of sub-tile (i, j): g-channel gb + NI*(8q+4half+e) + j,
+    // a-channel ab + MI*l31 + i.  For fixed (i, q) the NI*4 values over (e, j) are consecutive g-channels: 16-byte stores.
+    const int ab = m0 + wm * 32 * MI + MI * l31, gb = n0 + wn * 32 * NI;
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
+    for (int i = 0; i < MI; ++i) {
+      const int row = ab + i;
+      if (row < ca) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int col = n0 + j * 32 + 8 * q + 4 * half;
-          if (col < cg) *(float4 *)&dst[(int64_t)row * cg + col] = make_float4(acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
+          float v[4 * NI];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) v[e * NI + j] = acc[i][j][4 * q + e];
+          const int col = gb + NI * (8 * q + 4 * half);
+#pragma unroll
+          for (int t = 0; t < NI; ++t)
+            if (col + 4 * t < cg) *(float4 *)&dst[(int64_t)row * cg + col + 4 * t] = make_float4(v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]);
         }
+      }
     }
   }
 }
 
-// dW[k] = sum of the partial tiles of offset k (tiles are numbered in offset order).  Block =
-// (256/TL) float4 columns x TL tile lanes; lane l sums tiles l, l+TL, ... and the TL lane sums are
+// dW[k] = sum of the partial tiles of offset k (tiles are numbered in offset order); an offset with ONE tile was written by the
+// main kernel itself.  Block = (256/TL) float4 columns x TL tile lanes; lane l sums tiles l, l+TL, ... and the TL lane sums are
 // added in lane order through LDS: a fixed summation tree, bit-reproducible.
 template <int TL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, const int32_t *__restrict__ koff, int kvol,
@@ -646,6 +703,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     int nt = (c + tile_len - 1) / tile_len;
     if (q < k) first += nt; else cnt = nt;
   }
+  if (cnt == 1) return;   // written directly by pairs_wgrad_kernel (block-uniform exit)
   const int col = threadIdx.x % COLS, tl = threadIdx.x / COLS;
   const int64_t e = ((int64_t)blockIdx.x * COLS + col) * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -669,24 +727,31 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
   if (tl == 0 && e < mat) *(float4 *)&dW[(int64_t)k * mat + e] = s;
 }
 
-static void wgrad_config(int ca, int cg, int *wm, int *nt) {
-  *wm = ca <= 32 ? 1 : (ca <= 64 ? 2 : 4);
-  int n = cg >= 128 ? 4 : (cg + 31) / 32;
-  if (cg > 128 && cg % 96 == 0 && cg % 128 != 0) n = 3;
-  *nt = n;
+// Tile shape per channel count.  M side: 32 / 64 / 96 (multiples of 96 that are not multiples of 128: 96, 192) / 128;
+// N side: 32 / 64 / 96 / 128.
+struct WgradCfg { int mi, wmg, ni, wng; };
+static WgradCfg wgrad_config(int ca, int cg) {
+  WgradCfg c;
+  if (ca <= 32) { c.mi = 1; c.wmg = 1; }
+  else if (ca <= 64) { c.mi = 2; c.wmg = 1; }
+  else if (ca % 96 == 0 && ca % 128 != 0) { c.mi = 3; c.wmg = 1; }
+  else { c.mi = 2; c.wmg = 2; }
+  if (cg <= 32) { c.ni = 1; c.wng = 1; }
+  else if (cg <= 64) { c.ni = 2; c.wng = 1; }
+  else if (cg % 96 == 0 && cg % 128 != 0) { c.ni = 3; c.wng = 1; }
+  else { c.ni = 2; c.wng = 2; }
+  return c;
 }
 
-// pairs per tile: aim at ~4 blocks per CU over all (tile, M-tile, N-tile) blocks, 128..4096 pairs (measured over the 20
-// layers of tools/bench_spconv.py: 768 / 1024 / 1280 / 1536 / 2048 blocks -> 1336 / 1275 / 1316 / 1304 / 1360 us)
+// pairs per tile: aim at `FTX_WGRAD_BLOCKS` blocks over all (tile, M-tile, N-tile) blocks, 256..8192 pairs
 static int wgrad_tile_len(int64_t n_pairs, int ca, int cg, int kvol) {
-  int wm, nt;
-  wgrad_config(ca, cg, &wm, &nt);
-  static const int target = getenv("FTX_WGRAD_BLOCKS") ? atoi(getenv("FTX_WGRAD_BLOCKS")) : 1024;
-  int64_t mn_tiles = ceil_div(ca, 32 * wm) * ceil_div(cg, 32 * nt);
+  const WgradCfg c = wgrad_config(ca, cg);
+  static const int target = getenv("FTX_WGRAD_BLOCKS") ? atoi(getenv("FTX_WGRAD_BLOCKS")) : 768;
+  int64_t mn_tiles = ceil_div(ca, 32 * c.mi * c.wmg) * ceil_div(cg, 32 * c.ni * c.wng);
   int64_t want_tiles = ceil_div(target, mn_tiles);
-  int64_t len = ceil_div(ceil_div(n_pairs, want_tiles), WG_BR) * WG_BR;
-  if (len < 128) len = 128;
-  if (len > 4096) len = 4096;
+  int64_t len = ceil_div(ceil_div(n_pairs, want_tiles), 2 * WG_BR) * 2 * WG_BR;
+  if (len < 256) len = 256;
+  if (len > 8192) len = 8192;
   return (int)len;
 }
 
@@ -698,15 +763,17 @@ extern "C" size_t ftx_spconv_pairs_wgrad_workspace_bytes(int64_t n_pairs, int32_
   return sizeof(float) * (size_t)wgrad_tiles_ub(n_pairs, len, kvol) * ca * cg;
 }
 
-template <int WM>
-static void launch_wgrad(int nt, dim3 grid, hipStream_t st, const float *A, int64_t rows_a, const int32_t *idx_a, const float *G, int64_t rows_g,
-                         const int32_t *idx_g, const int32_t *koff, int ca, int cg, int kvol, int ns, float *part, int n_dense) {
-  switch (nt) {
-    case 1: pairs_wgrad_kernel<WM, 1><<<grid, 256, 0, st>>>(A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part, n_dense); break;
-    case 2: pairs_wgrad_kernel<WM, 2><<<grid, 256, 0, st>>>(A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part, n_dense); break;
-    case 3: pairs_wgrad_kernel<WM, 3><<<grid, 256, 0, st>>>(A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part, n_dense); break;
-    default: pairs_wgrad_kernel<WM, 4><<<grid, 256, 0, st>>>(A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, ns, part, n_dense); break;
-  }
+template <int MI, int WMG>
+static void launch_wgrad_n(const WgradCfg &c, dim3 grid, hipStream_t st, const float *A, int64_t rows_a, const int32_t *idx_a, const float *G, int64_t rows_g,
+                           const int32_t *idx_g, const int32_t *koff, int ca, int cg, int kvol, int tl, float *part, float *dW, int n_dense) {
+  if (c.ni == 1)
+    pairs_wgrad_kernel<MI, 1, WMG, 1><<<grid, 256, 0, st>>>(A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, tl, part, dW, n_dense);
+  else if (c.ni == 3)
+    pairs_wgrad_kernel<MI, 3, WMG, 1><<<grid, 256, 0, st>>>(A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, tl, part, dW, n_dense);
+  else if (c.wng == 1)
+    pairs_wgrad_kernel<MI, 2, WMG, 1><<<grid, 256, 0, st>>>(A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, tl, part, dW, n_dense);
+  else
+    pairs_wgrad_kernel<MI, 2, WMG, 2><<<grid, 256, 0, st>>>(A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, tl, part, dW, n_dense);
 }
 
 extern "C" int ftx_spconv_pairs_wgrad(const float *A, int64_t rows_a, const int32_t *idx_a, const float *G, int64_t rows_g, const int32_t *idx_g,
@@ -734,15 +801,16 @@ extern "C" int ftx_spconv_pairs_wgrad(const float *A, int64_t rows_a, const int3
     return FTX_EWORKSPACE;
   }
   float *part = (float *)workspace;
-  int wm, nt;
-  wgrad_config(ca, cg, &wm, &nt);
-  dim3 grid((unsigned)tiles, (unsigned)ceil_div(ca, 32 * wm), (unsigned)ceil_div(cg, 32 * nt));
-  if (wm == 1)
-    launch_wgrad<1>(nt, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, tile_len, part, (int)n_pairs);
-  else if (wm == 2)
-    launch_wgrad<2>(nt, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, tile_len, part, (int)n_pairs);
+  const WgradCfg c = wgrad_config(ca, cg);
+  dim3 grid((unsigned)tiles, (unsigned)ceil_div(ca, 32 * c.mi * c.wmg), (unsigned)ceil_div(cg, 32 * c.ni * c.wng));
+  if (c.mi == 1)
+    launch_wgrad_n<1, 1>(c, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, tile_len, part, dW, (int)n_pairs);
+  else if (c.mi == 3)
+    launch_wgrad_n<3, 1>(c, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, tile_len, part, dW, (int)n_pairs);
+  else if (c.wmg == 1)
+    launch_wgrad_n<2, 1>(c, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, tile_len, part, dW, (int)n_pairs);
   else
-    launch_wgrad<4>(nt, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, tile_len, part, (int)n_pairs);
+    launch_wgrad_n<2, 2>(c, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, tile_len, part, dW, (int)n_pairs);
   const int64_t avg_tiles = tiles / kvol;
   if (avg_tiles <= 4)
     wgrad_reduce_kernel<1><<<dim3((unsigned)ceil_div(mat / 4, 256), (unsigned)kvol), 256, 0, st>>>(part, koff, kvol, tile_len, (int)n_pairs, mat, dW);

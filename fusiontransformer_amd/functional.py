@@ -328,6 +328,23 @@ def _spconv_apply(A, W, gather, pos, koff, n_pairs, n_rows_out, co, w_transposed
     return out
 
 
+def _spconv_direct(A, W, gather, scatter, koff, n_pairs, n_rows_out, co, w_transposed):
+    """out[scatter[p]] = A[gather[p]] @ W[k(p)] in ONE launch, for maps whose destination side is a bijection of the pair list."""
+    L = _lib.load()
+    rows_a, ca = A.shape
+    kvol = koff.shape[0] - 1
+    if n_pairs != n_rows_out:
+        raise ValueError("direct sparse conv: the pair list must cover every destination row exactly once")
+    out = _empty((n_rows_out, co), F32, A)
+
+    def launch():
+        check(L.ftx_spconv_pairs_gemm_scatter(ptr(A), rows_a, ptr(gather), ptr(scatter), ptr(W), int(w_transposed), ptr(koff), n_pairs, ca, co, kvol,
+                                              ptr(out), n_rows_out, stream()), "ftx_spconv_pairs_gemm_scatter")
+
+    _log_launch("spconv_pairs_gemm", dict(pairs=n_pairs, n_out=n_rows_out, ca=ca, co=co, kvol=kvol, direct=True), launch)
+    return out
+
+
 def _spconv_wgrad(A, idx_a, G, idx_g, koff, n_pairs):
     L = _lib.load()
     rows_a, ca = A.shape
@@ -359,8 +376,12 @@ class _SparseConv(torch.autograd.Function):
         n_in, n_out = (km.n_out, km.n_in) if transposed else (km.n_in, km.n_out)
         if feats.shape != (n_in, ca) or km.kvol != kvol:
             raise ValueError(f"conv3d: shape mismatch feats {tuple(feats.shape)} kernel {tuple(kernel.shape)} map ({km.kvol},{n_in}->{n_out})")
-        gather, pos = (km.pair_out, km.pos_t) if transposed else (km.pair_in, km.pos)
-        out = _spconv_apply(feats, kernel, gather, pos, km.koff, km.n_pairs, n_out, co, 0)
+        if transposed and km.fine_bijective:
+            # every fine row is the destination of exactly one pair: the GEMM epilogue writes `out` itself
+            out = _spconv_direct(feats, kernel, km.pair_out, km.pair_in, km.koff, km.n_pairs, n_out, co, 0)
+        else:
+            gather, pos = (km.pair_out, km.pos_t) if transposed else (km.pair_in, km.pos)
+            out = _spconv_apply(feats, kernel, gather, pos, km.koff, km.n_pairs, n_out, co, 0)
         ctx.save_for_backward(feats, kernel)
         ctx.km, ctx.transposed = km, transposed
         return out
@@ -374,8 +395,11 @@ class _SparseConv(torch.autograd.Function):
         g_feats = g_kernel = None
         in_side, out_side = (km.pair_out, km.pair_in) if transposed else (km.pair_in, km.pair_out)
         if ctx.needs_input_grad[0]:
-            pos_in = km.pos if transposed else km.pos_t
-            g_feats = _spconv_apply(grad_out, kernel, out_side, pos_in, km.koff, km.n_pairs, feats.shape[0], ca, 1)
+            if not transposed and km.fine_bijective:
+                g_feats = _spconv_direct(grad_out, kernel, km.pair_out, km.pair_in, km.koff, km.n_pairs, feats.shape[0], ca, 1)
+            else:
+                pos_in = km.pos if transposed else km.pos_t
+                g_feats = _spconv_apply(grad_out, kernel, out_side, pos_in, km.koff, km.n_pairs, feats.shape[0], ca, 1)
         if ctx.needs_input_grad[1]:
             g_kernel = _spconv_wgrad(feats, in_side, grad_out, out_side, km.koff, km.n_pairs)
         return g_feats, g_kernel, None, None

@@ -166,6 +166,12 @@ int ftx_sample_down_bwd(const float *img, const float *grad_out, int32_t b, int3
  * koff (kvol+1) int32 DEVICE; tmp (n_pairs, co) fully written. */
 int ftx_spconv_pairs_gemm(const float *A, int64_t rows_a, const int32_t *gather, const float *W, int32_t w_transposed, const int32_t *koff, int64_t n_pairs, int32_t ca, int32_t co, int32_t kvol, float *tmp, void *stream);
 
+/* One-launch convolution when every destination row receives exactly one pair (the strided 2^3 map seen from its
+ * fine side: data gradient of the strided conv, forward of the transposed conv, models/spvcnn.py:38-50):
+ * out[scatter[p],:] = A[gather[p],:] @ Wk(p).  scatter (n_pairs) int32 must be injective; out (rows_out, co); rows not
+ * named by scatter are left untouched.  Replaces pairs_gemm + reduce (no tmp round trip). */
+int ftx_spconv_pairs_gemm_scatter(const float *A, int64_t rows_a, const int32_t *gather, const int32_t *scatter, const float *W, int32_t w_transposed, const int32_t *koff, int64_t n_pairs, int32_t ca, int32_t co, int32_t kvol, float *out, int64_t rows_out, void *stream);
+
 /* Dense rows on the same tile code: out[r,:] = A[r,:] @ W (+ bias), r < n.  W as above with kvol = 1;
  * bias (co) may be NULL.  Replaces the point-branch nn.Linear layers (models/spvcnn.py:164-180,
  * models/middle_fusion.py:18-29) and the kernel_size=1 spnn.Conv3d (spvcnn.py:71-75). */
