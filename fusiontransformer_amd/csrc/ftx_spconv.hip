@@ -740,6 +740,10 @@ static WgradCfg wgrad_config(int ca, int cg) {
   else if (cg <= 64) { c.ni = 2; c.wng = 1; }
   else if (cg % 96 == 0 && cg % 128 != 0) { c.ni = 3; c.wng = 1; }
   else { c.ni = 2; c.wng = 2; }
+  // a 96 x 96 tile per wave is 9 accumulators (144 registers): one wave per SIMD.  96 -> 96 layers take a 128 x 96 tile instead
+  // (2 x 3 accumulators per wave, the last 32 M rows are padding); FTX_WGRAD_M96=1 selects the 96 x 96 form for measurements.
+  static const int m96 = getenv("FTX_WGRAD_M96") ? atoi(getenv("FTX_WGRAD_M96")) : 0;
+  if (c.mi == 3 && c.ni == 3 && !m96) { c.mi = 2; c.wmg = 2; }
   return c;
 }
 
