@@ -502,7 +502,9 @@ __global__ __launch_bounds__(256) void pairs_wgrad_kernel(const float *__restric
   constexpr int LDSF = STAGE > RED ? STAGE : RED;
   __shared__ __attribute__((aligned(16))) float lds[LDSF];
   __shared__ int32_t s_ia[WG_ROUND], s_ig[WG_ROUND];
+  __shared__ uint8_t s_ok[WG_ROUND];
   __shared__ int s_tile[4];
+  __shared__ int s_bad;
   float *As = lds, *Gs = lds + WG_BR * TM;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -554,36 +556,57 @@ __global__ __launch_bounds__(256) void pairs_wgrad_kernel(const float *__restric
 
   // Two register stages: the gathers of step s+2 are issued while step s is in the matrix cores, so a block hides its own load
   // latency (blocks of one CU start together and stay in lockstep, so relying on the other resident blocks does not work).
+  //
+  // The gathers are UNCONDITIONAL loads from addresses that are always valid: the staged indices are clamped to real rows and the
+  // channel offset to the last float4 of a row.  What such a load brings in for a channel >= ca (cg) only ever reaches
+  // accumulator rows / columns >= ca (cg), which the epilogue never stores, so padded channels need no masking at all; pairs past
+  // the end of the tile (and pairs with an out-of-range index) are zeroed at LDS-store time, on a block-uniform slow path that a
+  // tile enters for its last step only.  (With a branch per load, as before, every load waited for its own index read:
+  // ~16 serialised LDS round trips per step.)
   constexpr int QA = TM / 32, QG = TN / 32;   // float4 per thread per step and operand
   float4 ra0[QA], rg0[QG], ra1[QA], rg1[QG];
   int rbase = lo, rend = lo;
+  int pra[QA], prg[QG], ca_off[QA], cg_off[QG];
+#pragma unroll
+  for (int q = 0; q < QA; ++q) {
+    int e = q * 256 + tid;
+    pra[q] = e / (TM / 4);
+    int c = m0 + (e - pra[q] * (TM / 4)) * 4;
+    ca_off[q] = c + 4 <= ca ? c : ca - 4;
+  }
+#pragma unroll
+  for (int q = 0; q < QG; ++q) {
+    int e = q * 256 + tid;
+    prg[q] = e / (TN / 4);
+    int c = n0 + (e - prg[q] * (TN / 4)) * 4;
+    cg_off[q] = c + 4 <= cg ? c : cg - 4;
+  }
   auto load_step = [&](int p0, float4 (&ra)[QA], float4 (&rg)[QG]) {
+    const int o = p0 - rbase;
+    if (o >= WG_ROUND) return;   // past this round's indices: the step is never consumed
+    int32_t ia[QA], ig[QG];
 #pragma unroll
-    for (int q = 0; q < QA; ++q) {
-      int e = q * 256 + tid;
-      int pr = e / (TM / 4), c4 = (e - pr * (TM / 4)) * 4;
-      int p = p0 + pr;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p < rend && m0 + c4 < ca) {
-        int32_t ia = s_ia[p - rbase];
-        if (ia >= 0) v = *(const float4 *)&A[(int64_t)ia * ca + m0 + c4];
-      }
-      ra[q] = v;
-    }
+    for (int q = 0; q < QA; ++q) ia[q] = s_ia[(o + pra[q]) & (WG_ROUND - 1)];
 #pragma unroll
-    for (int q = 0; q < QG; ++q) {
-      int e = q * 256 + tid;
-      int pr = e / (TN / 4), c4 = (e - pr * (TN / 4)) * 4;
-      int p = p0 + pr;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p < rend && n0 + c4 < cg) {
-        int32_t ig = s_ig[p - rbase];
-        if (ig >= 0) v = *(const float4 *)&G[(int64_t)ig * cg + n0 + c4];
-      }
-      rg[q] = v;
-    }
+    for (int q = 0; q < QG; ++q) ig[q] = s_ig[(o + prg[q]) & (WG_ROUND - 1)];
+#pragma unroll
+    for (int q = 0; q < QA; ++q) ra[q] = *(const float4 *)(A + ((int64_t)ia[q] * ca + ca_off[q]));
+#pragma unroll
+    for (int q = 0; q < QG; ++q) rg[q] = *(const float4 *)(G + ((int64_t)ig[q] * cg + cg_off[q]));
   };
-  auto store_step = [&](const float4 (&ra)[QA], const float4 (&rg)[QG]) {
+  auto store_step = [&](int p0, float4 (&ra)[QA], float4 (&rg)[QG]) {
+    if (p0 + WG_BR > rend || s_bad) {   // block-uniform: last step of the tile (or a malformed pair list)
+#pragma unroll
+      for (int q = 0; q < QA; ++q) {
+        const int p = p0 + pra[q];
+        if (p >= rend || s_ok[(p - rbase) & (WG_ROUND - 1)] == 0) ra[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int q = 0; q < QG; ++q) {
+        const int p = p0 + prg[q];
+        if (p >= rend || s_ok[(p - rbase) & (WG_ROUND - 1)] == 0) rg[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
 #pragma unroll
     for (int q = 0; q < QA; ++q) *(float4 *)&As[(q * 256 + tid) * 4] = ra[q];   // row-major [pair][TM]: e*4 == pr*TM + c4
 #pragma unroll
@@ -613,23 +636,37 @@ __global__ __launch_bounds__(256) void pairs_wgrad_kernel(const float *__restric
   for (rbase = lo; rbase < hi; rbase += WG_ROUND) {
     rend = (rbase + WG_ROUND < hi) ? rbase + WG_ROUND : hi;
     __syncthreads();  // previous round's gathers are done with s_ia / s_ig
-    for (int t = tid; t < rend - rbase; t += 256) {
-      int32_t ia = idx_a ? idx_a[rbase + t] : rbase + t, ig = idx_g ? idx_g[rbase + t] : rbase + t;
-      if (ia < 0 || ia >= rows_a || ig < 0 || ig >= rows_g) ia = ig = -1;
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    for (int t = tid; t < WG_ROUND; t += 256) {
+      // every slot gets a loadable row: slots past the end repeat row 0, malformed pairs are flagged and zeroed at store time
+      int32_t ia = 0, ig = 0;
+      uint8_t ok = 0;
+      if (t < rend - rbase) {
+        ia = idx_a ? idx_a[rbase + t] : rbase + t;
+        ig = idx_g ? idx_g[rbase + t] : rbase + t;
+        ok = 1;
+        if (ia < 0 || ia >= rows_a || ig < 0 || ig >= rows_g) {
+          ia = ig = 0;
+          ok = 0;
+          s_bad = 1;
+        }
+      }
       s_ia[t] = ia;
       s_ig[t] = ig;
+      s_ok[t] = ok;
     }
     __syncthreads();
     load_step(rbase, ra0, rg0);
     load_step(rbase + WG_BR, ra1, rg1);
     for (int p0 = rbase; p0 < rend; p0 += 2 * WG_BR) {
-      store_step(ra0, rg0);
+      store_step(p0, ra0, rg0);
       __syncthreads();
       load_step(p0 + 2 * WG_BR, ra0, rg0);
       mfma_step();
       __syncthreads();
       if (p0 + WG_BR >= rend) break;
-      store_step(ra1, rg1);
+      store_step(p0 + WG_BR, ra1, rg1);
       __syncthreads();
       load_step(p0 + 3 * WG_BR, ra1, rg1);
       mfma_step();
@@ -708,8 +745,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
   const int64_t e = ((int64_t)blockIdx.x * COLS + col) * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e < mat) {
-    for (int t = tl; t < cnt; t += TL) {
-      float4 v = *(const float4 *)&part[(int64_t)(first + t) * mat + e];
+    const float *src = part + (int64_t)first * mat + e;
+    int t = tl;
+    for (; t + 3 * TL < cnt; t += 4 * TL) {   // four independent loads in flight, added in tile order
+      float4 v0 = *(const float4 *)&src[(int64_t)t * mat], v1 = *(const float4 *)&src[(int64_t)(t + TL) * mat];
+      float4 v2 = *(const float4 *)&src[(int64_t)(t + 2 * TL) * mat], v3 = *(const float4 *)&src[(int64_t)(t + 3 * TL) * mat];
+      s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+      s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+      s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+      s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+    }
+    for (; t < cnt; t += TL) {
+      float4 v = *(const float4 *)&src[(int64_t)t * mat];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
   }
@@ -750,7 +797,7 @@ static WgradCfg wgrad_config(int ca, int cg) {
 // pairs per tile: aim at `FTX_WGRAD_BLOCKS` blocks over all (tile, M-tile, N-tile) blocks, 256..8192 pairs
 static int wgrad_tile_len(int64_t n_pairs, int ca, int cg, int kvol) {
   const WgradCfg c = wgrad_config(ca, cg);
-  static const int target = getenv("FTX_WGRAD_BLOCKS") ? atoi(getenv("FTX_WGRAD_BLOCKS")) : 768;
+  static const int target = getenv("FTX_WGRAD_BLOCKS") ? atoi(getenv("FTX_WGRAD_BLOCKS")) : 512;
   int64_t mn_tiles = ceil_div(ca, 32 * c.mi * c.wmg) * ceil_div(cg, 32 * c.ni * c.wng);
   int64_t want_tiles = ceil_div(target, mn_tiles);
   int64_t len = ceil_div(ceil_div(n_pairs, want_tiles), 2 * WG_BR) * 2 * WG_BR;
@@ -792,7 +839,7 @@ extern "C" int ftx_spconv_pairs_wgrad(const float *A, int64_t rows_a, const int3
     if (hipMemsetAsync(dW, 0, sizeof(float) * kvol * mat, st) != hipSuccess) return check_launch("ftx_spconv_pairs_wgrad memset");
     return FTX_OK;
   }
-  FTX_REQUIRE(A && G, "ftx_spconv_pairs_wgrad: null pointer");
+  FTX_REQUIRE(A && G && rows_a >= 1 && rows_g >= 1, "ftx_spconv_pairs_wgrad: null pointer or empty operand");
   const bool dense = (idx_a == nullptr && idx_g == nullptr && koff == nullptr);
   FTX_REQUIRE(dense || (idx_a && idx_g && koff), "ftx_spconv_pairs_wgrad: idx_a, idx_g and koff must be all set or all null (dense rows)");
   FTX_REQUIRE(!dense || (kvol == 1 && n_pairs <= rows_a && n_pairs <= rows_g), "ftx_spconv_pairs_wgrad: dense mode needs kvol == 1 and n_pairs rows in A and G");
@@ -815,7 +862,8 @@ extern "C" int ftx_spconv_pairs_wgrad(const float *A, int64_t rows_a, const int3
     launch_wgrad_n<2, 1>(c, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, tile_len, part, dW, (int)n_pairs);
   else
     launch_wgrad_n<2, 2>(c, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, tile_len, part, dW, (int)n_pairs);
-  const int64_t avg_tiles = tiles / kvol;
+  // the centre offset of a submanifold map holds ~6x the average pair count: size the tile lanes for it, not for the average
+  const int64_t avg_tiles = kvol > 1 ? 6 * tiles / kvol : tiles;
   if (avg_tiles <= 4)
     wgrad_reduce_kernel<1><<<dim3((unsigned)ceil_div(mat / 4, 256), (unsigned)kvol), 256, 0, st>>>(part, koff, kvol, tile_len, (int)n_pairs, mat, dW);
   else if (avg_tiles <= 32)

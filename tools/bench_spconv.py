@@ -9,7 +9,10 @@ from fusiontransformer_amd.models.utils import initial_voxelize
 from fusiontransformer_amd.sparse import PointTensor
 
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=4); ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--filter", default="", help="only layers whose name contains one of these comma-separated substrings")
+ap.add_argument("--what", default="gemm,reduce,wgrad", help="kernels to run (profiling runs: --what wgrad --iters 1)")
 args = ap.parse_args()
+WHAT = set(args.what.split(","))
 b = make_batch(list(range(args.batch)))
 z = PointTensor(torch.from_numpy(b["feats"]).cuda(), torch.from_numpy(b["coords"]).float().cuda())
 x0 = initial_voxelize(z, 1, 1)
@@ -24,7 +27,9 @@ for lvl, (s, chans) in enumerate([(1, [(32, 32), (128, 96), (96, 96)]), (2, [(32
 for s, c in [(1, 32), (2, 32), (4, 64), (8, 128)]:
     layers.append(("k2 down s%d %d->%d" % (s, c, c), 2, s, 2, c, c))
 
-def timeit(fn):
+def timeit(fn, on=True):
+    if not on:
+        return float("nan")
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -35,14 +40,19 @@ def timeit(fn):
 print("%-24s %9s %9s | %8s %8s %8s | %7s %7s" % ("layer", "rows", "pairs", "gemm us", "reduce", "wgrad", "gemmTF", "wgradTF"))
 tot = [0, 0, 0]
 for name, ks, cur, st, ca, co in layers:
+    if args.filter and not any(f in name for f in args.filter.split(",")):
+        continue
     km = cm.kernel_map(ks, cur, st)
     A = torch.randn(km.n_in, ca, device="cuda"); W = torch.randn(ks ** 3, ca, co, device="cuda") * 0.05
     G = torch.randn(km.n_out, co, device="cuda")
     L = spf._lib.load()
     tmp = torch.empty(km.n_pairs, co, device="cuda"); out = torch.empty(km.n_out, co, device="cuda")
-    t_g = timeit(lambda: L.ftx_spconv_pairs_gemm(A.data_ptr(), km.n_in, km.pair_in.data_ptr(), W.data_ptr(), int(os.environ.get("FTX_BENCH_WT", "0")), km.koff.data_ptr(), km.n_pairs, ca, co, ks ** 3, tmp.data_ptr(), spf.stream()))
-    t_r = timeit(lambda: L.ftx_spconv_reduce(tmp.data_ptr(), km.pos.data_ptr(), km.n_out, co, ks ** 3, out.data_ptr(), spf.stream()))
-    t_w = timeit(lambda: spf._spconv_wgrad(A, km.pair_in, G, km.pair_out, km.koff, km.n_pairs))
+    t_g = timeit(lambda: L.ftx_spconv_pairs_gemm(A.data_ptr(), km.n_in, km.pair_in.data_ptr(), W.data_ptr(), int(os.environ.get("FTX_BENCH_WT", "0")), km.koff.data_ptr(), km.n_pairs, ca, co, ks ** 3, tmp.data_ptr(), spf.stream()), "gemm" in WHAT)
+    t_r = timeit(lambda: L.ftx_spconv_reduce(tmp.data_ptr(), km.pos.data_ptr(), km.n_out, co, ks ** 3, out.data_ptr(), spf.stream()), "reduce" in WHAT)
+    ws_bytes = int(L.ftx_spconv_pairs_wgrad_workspace_bytes(km.n_pairs, ca, co, ks ** 3))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda"); dW = torch.empty(ks ** 3, ca, co, device="cuda")
+    t_w = timeit(lambda: L.ftx_spconv_pairs_wgrad(A.data_ptr(), km.n_in, km.pair_in.data_ptr(), G.data_ptr(), km.n_out, km.pair_out.data_ptr(), km.koff.data_ptr(),
+                                                  km.n_pairs, ca, co, ks ** 3, dW.data_ptr(), ws.data_ptr(), ws_bytes, spf.stream()), "wgrad" in WHAT)
     fl = 2.0 * km.n_pairs * ca * co
     print("%-24s %9d %9d | %8.1f %8.1f %8.1f | %7.1f %7.1f" % (name, km.n_out, km.n_pairs, t_g, t_r, t_w, fl / t_g / 1e6, fl / t_w / 1e6))
     tot[0] += t_g; tot[1] += t_r; tot[2] += t_w
