@@ -190,13 +190,18 @@ __global__ __launch_bounds__(256) void pairs_gemm_kernel(const float *__restrict
   const int n0 = blockIdx.y * BN;
   const int arow = tid >> 3, acol = (tid & 7) * 4;
 
+  // Gathers are unconditional loads from addresses that are always valid: rows past the end of the tile (and malformed
+  // indices) read row 0 -- what they produce lands in accumulator rows the epilogue never stores (or zeroes) -- and a column
+  // tile that sticks out of W re-reads W's last float4.  Only a reduction dimension that is not a multiple of BK (the 4-channel
+  // stem) needs zero fill, on a uniform slow path.  (A branch per load kept every load behind its own compare.)
+  const bool kfull = (ca % BK) == 0;
   int32_t src[A_PASSES];
 #pragma unroll
   for (int p = 0; p < A_PASSES; ++p) {
     int r = p * 32 + arow;
-    int32_t s = -1;
+    int32_t s = 0;
     if (r < cnt) s = gather ? gather[p0 + r] : p0 + r;
-    if (s >= rows_a) s = -1;
+    if (s < 0 || s >= rows_a) s = 0;
     src[p] = s;
   }
   const float *Wk = W + (int64_t)k * ca * co;
@@ -211,19 +216,37 @@ __global__ __launch_bounds__(256) void pairs_gemm_kernel(const float *__restrict
 
   float4 ra[A_PASSES], rb[B_PASSES];
   auto load_chunk = [&](int c0) {
+    if (kfull) {
+#pragma unroll
+      for (int p = 0; p < A_PASSES; ++p) ra[p] = *(const float4 *)&A[(int64_t)src[p] * ca + c0 + acol];
+#pragma unroll
+      for (int q = 0; q < B_PASSES; ++q) {
+        if (!w_transposed) {  // W[k] stored (ca, co): 16 bytes along co; a wave covers 8 k-rows x 128 B
+          int kk = ((tid >> 6) << 3) + (tid & 7), n4 = n0 + (q * 8 + ((tid >> 3) & 7)) * 4;
+          n4 = n4 + 4 <= co ? n4 : co - 4;
+          rb[q] = *(const float4 *)&Wk[(int64_t)(c0 + kk) * co + n4];
+        } else {              // W[k] stored (co, ca): 16 bytes along ca
+          int e = q * 256 + tid;
+          int nn = n0 + (e >> 3), k4 = (e & 7) * 4;
+          nn = nn < co ? nn : co - 1;
+          rb[q] = *(const float4 *)&Wk[(int64_t)nn * ca + c0 + k4];
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (src[p] >= 0 && c0 + acol < ca) v = *(const float4 *)&A[(int64_t)src[p] * ca + c0 + acol];
+      if (c0 + acol < ca) v = *(const float4 *)&A[(int64_t)src[p] * ca + c0 + acol];
       ra[p] = v;
     }
 #pragma unroll
     for (int q = 0; q < B_PASSES; ++q) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!w_transposed) {  // W[k] stored (ca, co): 16 bytes along co; a wave covers 8 k-rows x 128 B
+      if (!w_transposed) {
         int kk = ((tid >> 6) << 3) + (tid & 7), n4 = (q * 8 + ((tid >> 3) & 7)) * 4;
         if (c0 + kk < ca && n0 + n4 < co) v = *(const float4 *)&Wk[(int64_t)(c0 + kk) * co + n0 + n4];
-      } else {              // W[k] stored (co, ca): 16 bytes along ca
+      } else {
         int e = q * 256 + tid;
         int nn = e >> 3, k4 = (e & 7) * 4;
         if (n0 + nn < co && c0 + k4 < ca) v = *(const float4 *)&Wk[(int64_t)(n0 + nn) * ca + c0 + k4];
@@ -290,10 +313,16 @@ __global__ __launch_bounds__(256) void pairs_gemm_kernel(const float *__restrict
   // ---- W is the MFMA's row operand, so lane (pair l31, half) holds 4 consecutive output channels in every 4
   // consecutive accumulator registers: 16-byte stores, each pair row receives 32 contiguous bytes per instruction
   // (dword stores of the (pair, channel) orientation took 17k cycles per tile here, these take 6k)
+  const bool nfull = n0 + BN <= co;
 #pragma unroll
   for (int r = 0; r < RT; ++r) {
     const int row = wave * 32 * RT + r * 32 + l31;
     int64_t drow = row < cnt ? p0 + row : -1;
+    bool zero = false;   // a pair whose source index is out of range contributes a zero row, as if it gathered zeros
+    if (gather != nullptr && drow >= 0) {
+      const int32_t sidx = gather[drow];
+      zero = sidx < 0 || sidx >= rows_a;
+    }
     if (scatter != nullptr && drow >= 0) {
       drow = scatter[drow];
       if (drow >= rows_out) drow = -1;
@@ -305,8 +334,9 @@ __global__ __launch_bounds__(256) void pairs_gemm_kernel(const float *__restrict
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int col = n0 + j * 32 + 8 * q + 4 * half;
-          if (col < co) {
+          if (nfull || col < co) {
             float4 v = make_float4(acc[r][j][4 * q], acc[r][j][4 * q + 1], acc[r][j][4 * q + 2], acc[r][j][4 * q + 3]);
+            if (zero) v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (bias) {
               const float4 bv = *(const float4 *)&bias[col];
               v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
@@ -360,7 +390,7 @@ extern "C" int ftx_spconv_pairs_gemm(const float *A, int64_t rows_a, const int32
   FTX_REQUIRE(n_pairs >= 0 && rows_a >= 0 && kvol >= 1 && kvol <= 64, "ftx_spconv_pairs_gemm: bad size");
   FTX_REQUIRE(ca >= 4 && ca % 4 == 0 && co >= 4 && co % 4 == 0, "ftx_spconv_pairs_gemm: channels must be multiples of 4 (ca=%d co=%d)", ca, co);
   if (n_pairs == 0) return FTX_OK;
-  FTX_REQUIRE(A && gather && W && koff && tmp, "ftx_spconv_pairs_gemm: null pointer");
+  FTX_REQUIRE(A && gather && W && koff && tmp && rows_a >= 1, "ftx_spconv_pairs_gemm: null pointer or empty operand");
   hipStream_t st = (hipStream_t)stream;
   const int nt = gemm_nt(co), rt = gemm_rt(n_pairs, kvol, ca, co);
   const unsigned tiles_ub = (unsigned)(ceil_div(n_pairs, TILE_P * rt) + kvol);  // sum_k ceil(cnt_k/tile) <= P/tile + kvol
@@ -385,7 +415,7 @@ extern "C" int ftx_spconv_pairs_gemm_scatter(const float *A, int64_t rows_a, con
   FTX_REQUIRE(n_pairs >= 0 && rows_a >= 0 && rows_out >= 0 && kvol >= 1 && kvol <= 64, "ftx_spconv_pairs_gemm_scatter: bad size");
   FTX_REQUIRE(ca >= 4 && ca % 4 == 0 && co >= 4 && co % 4 == 0, "ftx_spconv_pairs_gemm_scatter: channels must be multiples of 4 (ca=%d co=%d)", ca, co);
   if (n_pairs == 0) return FTX_OK;
-  FTX_REQUIRE(A && gather && scatter && W && koff && out, "ftx_spconv_pairs_gemm_scatter: null pointer");
+  FTX_REQUIRE(A && gather && scatter && W && koff && out && rows_a >= 1, "ftx_spconv_pairs_gemm_scatter: null pointer or empty operand");
   hipStream_t st = (hipStream_t)stream;
   const int nt = gemm_nt(co);
   dim3 grid((unsigned)(ceil_div(n_pairs, TILE_P) + kvol), (unsigned)ceil_div(co, 32 * nt));
@@ -742,36 +772,41 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
   }
   if (cnt == 1) return;   // written directly by pairs_wgrad_kernel (block-uniform exit)
   const int col = threadIdx.x % COLS, tl = threadIdx.x / COLS;
-  const int64_t e = ((int64_t)blockIdx.x * COLS + col) * 4;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (e < mat) {
-    const float *src = part + (int64_t)first * mat + e;
-    int t = tl;
-    for (; t + 3 * TL < cnt; t += 4 * TL) {   // four independent loads in flight, added in tile order
-      float4 v0 = *(const float4 *)&src[(int64_t)t * mat], v1 = *(const float4 *)&src[(int64_t)(t + TL) * mat];
-      float4 v2 = *(const float4 *)&src[(int64_t)(t + 2 * TL) * mat], v3 = *(const float4 *)&src[(int64_t)(t + 3 * TL) * mat];
-      s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
-      s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
-      s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
-      s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
-    }
-    for (; t < cnt; t += TL) {
-      float4 v = *(const float4 *)&src[(int64_t)t * mat];
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-  }
-  if (TL > 1) {
-    sh[tl][col] = s;
-    __syncthreads();
-    if (tl == 0) {
-#pragma unroll
-      for (int l = 1; l < TL; ++l) {
-        float4 v = sh[l][col];
+  const int64_t chunks = ceil_div(mat / 4, COLS);
+  // a block walks several column chunks: thousands of 4-KB blocks are bound by workgroup dispatch, not by bytes
+  for (int64_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+    const int64_t e = (chunk * COLS + col) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < mat) {
+      const float *src = part + (int64_t)first * mat + e;
+      int t = tl;
+      for (; t + 3 * TL < cnt; t += 4 * TL) {   // four independent loads in flight, added in tile order
+        float4 v0 = *(const float4 *)&src[(int64_t)t * mat], v1 = *(const float4 *)&src[(int64_t)(t + TL) * mat];
+        float4 v2 = *(const float4 *)&src[(int64_t)(t + 2 * TL) * mat], v3 = *(const float4 *)&src[(int64_t)(t + 3 * TL) * mat];
+        s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+        s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+        s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+        s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+      }
+      for (; t < cnt; t += TL) {
+        float4 v = *(const float4 *)&src[(int64_t)t * mat];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
     }
+    if (TL > 1) {
+      sh[tl][col] = s;
+      __syncthreads();
+      if (tl == 0) {
+#pragma unroll
+        for (int l = 1; l < TL; ++l) {
+          float4 v = sh[l][col];
+          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+      }
+      __syncthreads();
+    }
+    if (tl == 0 && e < mat) *(float4 *)&dW[(int64_t)k * mat + e] = s;
   }
-  if (tl == 0 && e < mat) *(float4 *)&dW[(int64_t)k * mat + e] = s;
 }
 
 // Tile shape per channel count.  M side: 32 / 64 / 96 (multiples of 96 that are not multiples of 128: 96, 192) / 128;
@@ -794,15 +829,63 @@ static WgradCfg wgrad_config(int ca, int cg) {
   return c;
 }
 
-// pairs per tile: aim at `FTX_WGRAD_BLOCKS` blocks over all (tile, M-tile, N-tile) blocks, 256..8192 pairs
+// Resident blocks per CU of the instantiation a layer uses (registers / LDS decide: 2 for the 128-wide tiles, up to 8 for 32 x 32),
+// asked from the runtime once per instantiation; 2 when there is no device to ask (the workspace query on a CPU-only host).
+template <int MI, int NI, int WMG, int WNG>
+static int wgrad_occ_of() {
+  static int occ = 0;
+  if (occ == 0) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pairs_wgrad_kernel<MI, NI, WMG, WNG>, 256, 0) != hipSuccess || n < 1) {
+      (void)hipGetLastError();
+      n = 2;
+    }
+    occ = n > 8 ? 8 : n;
+  }
+  return occ;
+}
+template <int MI, int WMG>
+static int wgrad_occ_n(const WgradCfg &c) {
+  if (c.ni == 1) return wgrad_occ_of<MI, 1, WMG, 1>();
+  if (c.ni == 3) return wgrad_occ_of<MI, 3, WMG, 1>();
+  if (c.wng == 1) return wgrad_occ_of<MI, 2, WMG, 1>();
+  return wgrad_occ_of<MI, 2, WMG, 2>();
+}
+static int wgrad_occ(const WgradCfg &c) {
+  if (c.mi == 1) return wgrad_occ_n<1, 1>(c);
+  if (c.mi == 3) return wgrad_occ_n<3, 1>(c);
+  if (c.wmg == 1) return wgrad_occ_n<2, 1>(c);
+  return wgrad_occ_n<2, 2>(c);
+}
+static int device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) {
+      (void)hipGetLastError();
+      n = 256;
+    }
+    cus = n;
+  }
+  return cus;
+}
+
+// Pairs per tile.  All blocks of a launch should be resident together: a launch of 1.2x the resident slots takes as long as one of 2x
+// (measured: 620 blocks on 512 slots ran 1.7x longer than 820).  So the tile length is chosen for R full rounds of
+// slots = CUs x resident blocks per CU, R as small as keeps a tile <= 4096 pairs; every offset adds about half a tile of rounding.
 static int wgrad_tile_len(int64_t n_pairs, int ca, int cg, int kvol) {
   const WgradCfg c = wgrad_config(ca, cg);
-  static const int target = getenv("FTX_WGRAD_BLOCKS") ? atoi(getenv("FTX_WGRAD_BLOCKS")) : 512;
-  int64_t mn_tiles = ceil_div(ca, 32 * c.mi * c.wmg) * ceil_div(cg, 32 * c.ni * c.wng);
-  int64_t want_tiles = ceil_div(target, mn_tiles);
-  int64_t len = ceil_div(ceil_div(n_pairs, want_tiles), 2 * WG_BR) * 2 * WG_BR;
+  static const int forced = getenv("FTX_WGRAD_BLOCKS") ? atoi(getenv("FTX_WGRAD_BLOCKS")) : 0;
+  const int64_t mn_tiles = ceil_div(ca, 32 * c.mi * c.wmg) * ceil_div(cg, 32 * c.ni * c.wng);
+  const int64_t slots = forced > 0 ? forced : (int64_t)device_cus() * wgrad_occ(c);
+  int64_t len = 256;
+  for (int rounds = 1; rounds <= 64; ++rounds) {
+    int64_t tiles = (slots * rounds * 15 / 16) / mn_tiles - (kvol + 1) / 2;   // 1/16 of head room: an overshoot costs a whole round
+    if (tiles < 1) tiles = 1;
+    len = ceil_div(ceil_div(n_pairs, tiles), 2 * WG_BR) * 2 * WG_BR;
+    if (len <= 4096) break;
+  }
   if (len < 256) len = 256;
-  if (len > 8192) len = 8192;
   return (int)len;
 }
 
@@ -863,12 +946,14 @@ extern "C" int ftx_spconv_pairs_wgrad(const float *A, int64_t rows_a, const int3
   else
     launch_wgrad_n<2, 2>(c, grid, st, A, rows_a, idx_a, G, rows_g, idx_g, koff, ca, cg, kvol, tile_len, part, dW, (int)n_pairs);
   // the centre offset of a submanifold map holds ~6x the average pair count: size the tile lanes for it, not for the average
-  const int64_t avg_tiles = kvol > 1 ? 6 * tiles / kvol : tiles;
-  if (avg_tiles <= 4)
-    wgrad_reduce_kernel<1><<<dim3((unsigned)ceil_div(mat / 4, 256), (unsigned)kvol), 256, 0, st>>>(part, koff, kvol, tile_len, (int)n_pairs, mat, dW);
-  else if (avg_tiles <= 32)
-    wgrad_reduce_kernel<4><<<dim3((unsigned)ceil_div(mat / 4, 64), (unsigned)kvol), 256, 0, st>>>(part, koff, kvol, tile_len, (int)n_pairs, mat, dW);
+  const int64_t big_tiles = kvol > 1 ? 6 * tiles / kvol : tiles;
+  const int64_t want_blocks = ceil_div(1024, kvol);   // ~4 blocks per CU over all offsets
+  auto rgrid = [&](int cols) { int64_t c = ceil_div(mat / 4, cols); return dim3((unsigned)(c < want_blocks ? c : want_blocks), (unsigned)kvol); };
+  if (big_tiles <= 4)
+    wgrad_reduce_kernel<1><<<rgrid(256), 256, 0, st>>>(part, koff, kvol, tile_len, (int)n_pairs, mat, dW);
+  else if (big_tiles <= 32)
+    wgrad_reduce_kernel<4><<<rgrid(64), 256, 0, st>>>(part, koff, kvol, tile_len, (int)n_pairs, mat, dW);
   else
-    wgrad_reduce_kernel<16><<<dim3((unsigned)ceil_div(mat / 4, 16), (unsigned)kvol), 256, 0, st>>>(part, koff, kvol, tile_len, (int)n_pairs, mat, dW);
+    wgrad_reduce_kernel<16><<<rgrid(16), 256, 0, st>>>(part, koff, kvol, tile_len, (int)n_pairs, mat, dW);
   return check_launch("ftx_spconv_pairs_wgrad");
 }
