@@ -57,6 +57,9 @@ SIGNATURES = {
     "ftx_spconv_pairs_gemm_scatter": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "ftx_rows_gemm": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "ftx_spconv_reduce": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "ftx_spconv_reduce_stats_blocks": (_i32, [_i64, _i32]),
+    "ftx_spconv_reduce_stats": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "ftx_bn_train_fwd_partials": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
     "ftx_spconv_pairs_wgrad_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "ftx_spconv_pairs_wgrad": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "ftx_bn_workspace_bytes": (_sz, [_i64, _i32]),

@@ -180,6 +180,21 @@ extern "C" int ftx_bn_train_fwd(const float *x, const float *residual, const flo
   return check_launch("ftx_bn_train_fwd");
 }
 
+// BatchNorm forward whose statistics were produced by the pass that wrote x (ftx_spconv_reduce_stats): `part` holds nb
+// per-block partial (sum, sum of squares) rows, float64.  Finalize + apply only: x is read once instead of twice.
+extern "C" int ftx_bn_train_fwd_partials(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean,
+                                         float *running_var, float momentum, float eps, int64_t n, int32_t c, int32_t relu, float *y,
+                                         float *save_mean, float *save_invstd, const double *part, int32_t nb, void *stream) {
+  int rc = bn_check("ftx_bn_train_fwd_partials", n, c);
+  if (rc != FTX_OK) return rc;
+  FTX_REQUIRE(n >= 1 && nb >= 1, "ftx_bn_train_fwd_partials: needs at least one row and one partial");
+  FTX_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && part, "ftx_bn_train_fwd_partials: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  bn_finalize_fwd_kernel<<<ceil_div(c, 4), 256, 0, st>>>(part, nb, n, c, eps, momentum, running_mean, running_var, save_mean, save_invstd);
+  bn_apply_fwd_kernel<<<grid_for(n * (c / 4), 256), 256, 0, st>>>(x, residual, gamma, beta, save_mean, save_invstd, n, c, relu, y);
+  return check_launch("ftx_bn_train_fwd_partials");
+}
+
 __global__ void bn_apply_eval_kernel(const float *__restrict__ x, const float *__restrict__ res, const float *__restrict__ gamma,
                                      const float *__restrict__ beta, const float *__restrict__ rm, const float *__restrict__ rv, float eps,
                                      int64_t n, int c, int relu, float *__restrict__ y) {

@@ -498,6 +498,93 @@ extern "C" int ftx_spconv_reduce(const float *tmp, const int32_t *pos, int64_t n
   return check_launch("ftx_spconv_reduce");
 }
 
+// The same reduce, also producing the BatchNorm statistics of its output (sum and sum of squares per channel, float64) as
+// per-block partials: the BatchNorm that follows every convolution (models/spvcnn.py:22-35,53-79) then needs no pass of its own
+// over `out`.  Block = (256 / (co/4)) rows x co/4 float4 columns over a contiguous row range; a thread keeps one column, so its
+// eight float64 sums stay in registers; rows of a block are summed in a fixed order and blocks are combined in block order by
+// ftx_bn_train_fwd_partials: the statistics do not depend on the launch geometry beyond `nb`, and are bit-reproducible.
+template <int KVOL>
+__global__ __launch_bounds__(256) void spconv_reduce_stats_kernel(const float *__restrict__ tmp, const int32_t *__restrict__ pos, int64_t n, int co,
+                                                                  int kvol, float *__restrict__ out, double *__restrict__ part) {
+  extern __shared__ double sh[];  // [2][RL][co]
+  const int cv = co >> 2;
+  const int RL = 256 / cv;
+  const int tid = threadIdx.x;
+  const int cg = tid % cv, rl = tid / cv;
+  const int64_t rows_per_block = ceil_div(n, (int64_t)gridDim.x);
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < n) ? r0 + rows_per_block : n;
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  if (rl < RL) {
+    const int j = cg * 4;
+    for (int64_t r = r0 + rl; r < r1; r += RL) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (KVOL > 0) {
+        int32_t p[KVOL > 0 ? KVOL : 1];
+#pragma unroll
+        for (int k = 0; k < KVOL; ++k) p[k] = pos[(int64_t)k * n + r];
+#pragma unroll
+        for (int k = 0; k < KVOL; ++k) {
+          if (p[k] >= 0) {
+            float4 v = *(const float4 *)&tmp[(int64_t)p[k] * co + j];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+          }
+        }
+      } else {
+        for (int k = 0; k < kvol; ++k) {
+          int32_t q = pos[(int64_t)k * n + r];
+          if (q >= 0) {
+            float4 v = *(const float4 *)&tmp[(int64_t)q * co + j];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+          }
+        }
+      }
+      *(float4 *)&out[r * co + j] = acc;
+      s0[0] += (double)acc.x; s1[0] += (double)acc.x * (double)acc.x;
+      s0[1] += (double)acc.y; s1[1] += (double)acc.y * (double)acc.y;
+      s0[2] += (double)acc.z; s1[2] += (double)acc.z * (double)acc.z;
+      s0[3] += (double)acc.w; s1[3] += (double)acc.w * (double)acc.w;
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      sh[(0 * RL + rl) * co + j + v] = s0[v];
+      sh[(1 * RL + rl) * co + j + v] = s1[v];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < 2 * co; e += 256) {
+    int which = e / co, col = e - which * co;
+    double s = 0;
+    for (int q = 0; q < RL; ++q) s += sh[(which * RL + q) * co + col];
+    part[((int64_t)blockIdx.x * 2 + which) * co + col] = s;
+  }
+}
+
+extern "C" int32_t ftx_spconv_reduce_stats_blocks(int64_t n, int32_t co) {
+  if (n <= 0 || co < 4) return 1;
+  const int rl = 256 / (co / 4) > 0 ? 256 / (co / 4) : 1;
+  int64_t b = ceil_div(n, 2 * rl);   // ~2 rows per thread
+  if (b > 2048) b = 2048;
+  return (int32_t)(b < 1 ? 1 : b);
+}
+
+extern "C" int ftx_spconv_reduce_stats(const float *tmp, const int32_t *pos, int64_t n, int32_t co, int32_t kvol, float *out, double *part,
+                                       int32_t nb, void *stream) {
+  FTX_REQUIRE(n >= 1 && kvol >= 1 && co >= 4 && co % 4 == 0 && co <= 1024, "ftx_spconv_reduce_stats: bad size");
+  FTX_REQUIRE(pos && out && part, "ftx_spconv_reduce_stats: null pointer");
+  FTX_REQUIRE(nb == ftx_spconv_reduce_stats_blocks(n, co), "ftx_spconv_reduce_stats: nb must come from ftx_spconv_reduce_stats_blocks");
+  hipStream_t st = (hipStream_t)stream;
+  const int rl = 256 / (co / 4);
+  const size_t lds = sizeof(double) * 2 * rl * co;
+  if (kvol == 27)
+    spconv_reduce_stats_kernel<27><<<nb, 256, lds, st>>>(tmp, pos, n, co, kvol, out, part);
+  else if (kvol == 8)
+    spconv_reduce_stats_kernel<8><<<nb, 256, lds, st>>>(tmp, pos, n, co, kvol, out, part);
+  else
+    spconv_reduce_stats_kernel<0><<<nb, 256, lds, st>>>(tmp, pos, n, co, kvol, out, part);
+  return check_launch("ftx_spconv_reduce_stats");
+}
+
 // ---------------------------------------------------------------------------------------
 // weight gradient: dW[k] = sum_{p in k} A[idx_a[p],:]^T @ G[idx_g[p],:]
 //

@@ -362,6 +362,38 @@ def _spconv_wgrad(A, idx_a, G, idx_g, koff, n_pairs):
     return dW
 
 
+def _conv_shapes(feats, kernel, km, transposed):
+    kvol, ca, co = kernel.shape
+    n_in, n_out = (km.n_out, km.n_in) if transposed else (km.n_in, km.n_out)
+    if feats.shape != (n_in, ca) or km.kvol != kvol:
+        raise ValueError(f"conv3d: shape mismatch feats {tuple(feats.shape)} kernel {tuple(kernel.shape)} map ({km.kvol},{n_in}->{n_out})")
+    return kvol, ca, co, n_in, n_out
+
+
+def _conv_forward(feats, kernel, km, transposed):
+    kvol, ca, co, n_in, n_out = _conv_shapes(feats, kernel, km, transposed)
+    if transposed and km.fine_bijective:
+        # every fine row is the destination of exactly one pair: the GEMM epilogue writes `out` itself
+        return _spconv_direct(feats, kernel, km.pair_out, km.pair_in, km.koff, km.n_pairs, n_out, co, 0)
+    gather, pos = (km.pair_out, km.pos_t) if transposed else (km.pair_in, km.pos)
+    return _spconv_apply(feats, kernel, gather, pos, km.koff, km.n_pairs, n_out, co, 0)
+
+
+def _conv_backward(feats, kernel, km, transposed, grad_out, need_feats, need_kernel):
+    kvol, ca, co = kernel.shape
+    g_feats = g_kernel = None
+    in_side, out_side = (km.pair_out, km.pair_in) if transposed else (km.pair_in, km.pair_out)
+    if need_feats:
+        if not transposed and km.fine_bijective:
+            g_feats = _spconv_direct(grad_out, kernel, km.pair_out, km.pair_in, km.koff, km.n_pairs, feats.shape[0], ca, 1)
+        else:
+            pos_in = km.pos if transposed else km.pos_t
+            g_feats = _spconv_apply(grad_out, kernel, out_side, pos_in, km.koff, km.n_pairs, feats.shape[0], ca, 1)
+    if need_kernel:
+        g_kernel = _spconv_wgrad(feats, in_side, grad_out, out_side, km.koff, km.n_pairs)
+    return g_feats, g_kernel
+
+
 class _SparseConv(torch.autograd.Function):
     """out[o] = sum over pairs (k, i->o) of feats[i] @ kernel[k].
 
@@ -372,16 +404,7 @@ class _SparseConv(torch.autograd.Function):
     def forward(ctx, feats, kernel, km, transposed):
         feats = req(feats.contiguous(), F32, "conv3d feats", 2)
         kernel = req(kernel.contiguous(), F32, "conv3d kernel", 3)
-        kvol, ca, co = kernel.shape
-        n_in, n_out = (km.n_out, km.n_in) if transposed else (km.n_in, km.n_out)
-        if feats.shape != (n_in, ca) or km.kvol != kvol:
-            raise ValueError(f"conv3d: shape mismatch feats {tuple(feats.shape)} kernel {tuple(kernel.shape)} map ({km.kvol},{n_in}->{n_out})")
-        if transposed and km.fine_bijective:
-            # every fine row is the destination of exactly one pair: the GEMM epilogue writes `out` itself
-            out = _spconv_direct(feats, kernel, km.pair_out, km.pair_in, km.koff, km.n_pairs, n_out, co, 0)
-        else:
-            gather, pos = (km.pair_out, km.pos_t) if transposed else (km.pair_in, km.pos)
-            out = _spconv_apply(feats, kernel, gather, pos, km.koff, km.n_pairs, n_out, co, 0)
+        out = _conv_forward(feats, kernel, km, transposed)
         ctx.save_for_backward(feats, kernel)
         ctx.km, ctx.transposed = km, transposed
         return out
@@ -389,19 +412,8 @@ class _SparseConv(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         feats, kernel = ctx.saved_tensors
-        km, transposed = ctx.km, ctx.transposed
         grad_out = req(grad_out.contiguous(), F32, "conv3d grad", 2)
-        kvol, ca, co = kernel.shape
-        g_feats = g_kernel = None
-        in_side, out_side = (km.pair_out, km.pair_in) if transposed else (km.pair_in, km.pair_out)
-        if ctx.needs_input_grad[0]:
-            if not transposed and km.fine_bijective:
-                g_feats = _spconv_direct(grad_out, kernel, km.pair_out, km.pair_in, km.koff, km.n_pairs, feats.shape[0], ca, 1)
-            else:
-                pos_in = km.pos if transposed else km.pos_t
-                g_feats = _spconv_apply(grad_out, kernel, out_side, pos_in, km.koff, km.n_pairs, feats.shape[0], ca, 1)
-        if ctx.needs_input_grad[1]:
-            g_kernel = _spconv_wgrad(feats, in_side, grad_out, out_side, km.koff, km.n_pairs)
+        g_feats, g_kernel = _conv_backward(feats, kernel, ctx.km, ctx.transposed, grad_out, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return g_feats, g_kernel, None, None
 
 
@@ -524,18 +536,9 @@ class _BatchNormTrain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        L = _lib.load()
         x, y, gamma, mean, invstd = ctx.saved_tensors
         gy = req(gy.contiguous(), F32, "bn grad", 2)
-        n, c = x.shape
-        gx = torch.empty_like(x)
-        gres = torch.empty_like(x) if ctx.has_res else None
-        ggamma = _empty((c,), F32, x)
-        gbeta = _empty((c,), F32, x)
-        ws_bytes = int(L.ftx_bn_workspace_bytes(n, c))
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
-        check(L.ftx_bn_train_bwd(ptr(gy), ptr(x), ptr(y), ptr(gamma), ptr(mean), ptr(invstd), n, c, ctx.relu, ptr(gx), ptr(gres), ptr(ggamma),
-                                 ptr(gbeta), ptr(ws), ws_bytes, stream()), "ftx_bn_train_bwd")
+        gx, gres, ggamma, gbeta = _bn_backward_launch(gy, x, y, gamma, mean, invstd, ctx.relu, ctx.has_res)
         return gx, gres, ggamma, gbeta, None, None, None, None, None
 
 
@@ -562,6 +565,82 @@ class _BatchNormEval(torch.autograd.Function):
         scale = gamma * torch.rsqrt(running_var + ctx.eps)
         gx = dy * scale
         return gx, (dy if ctx.has_res else None), None, None, None, None, None, None
+
+
+def _bn_backward_launch(gy, x, y, gamma, mean, invstd, relu, has_res):
+    L = _lib.load()
+    n, c = x.shape
+    gx = torch.empty_like(x)
+    gres = torch.empty_like(x) if has_res else None
+    ggamma = _empty((c,), F32, x)
+    gbeta = _empty((c,), F32, x)
+    ws_bytes = int(L.ftx_bn_workspace_bytes(n, c))
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+    check(L.ftx_bn_train_bwd(ptr(gy), ptr(x), ptr(y), ptr(gamma), ptr(mean), ptr(invstd), n, c, int(relu), ptr(gx), ptr(gres), ptr(ggamma),
+                             ptr(gbeta), ptr(ws), ws_bytes, stream()), "ftx_bn_train_bwd")
+    return gx, gres, ggamma, gbeta
+
+
+class _ConvBNTrain(torch.autograd.Function):
+    """spnn.Conv3d -> spnn.BatchNorm (training statistics) (-> + residual) (-> ReLU) as ONE autograd node
+    (models/spvcnn.py:22-35,38-50,53-79).  The reduce pass of the convolution produces the BatchNorm's batch statistics while
+    it writes the convolution output (ftx_spconv_reduce_stats), so that output is read once, by the apply pass, instead of twice;
+    one node instead of two also halves the host work per layer."""
+
+    @staticmethod
+    def forward(ctx, feats, kernel, km, transposed, residual, gamma, beta, running_mean, running_var, momentum, eps, relu):
+        L = _lib.load()
+        feats = req(feats.contiguous(), F32, "conv3d feats", 2)
+        kernel = req(kernel.contiguous(), F32, "conv3d kernel", 3)
+        kvol, ca, co, n_in, n_out = _conv_shapes(feats, kernel, km, transposed)
+        if residual is not None:
+            residual = req(residual.contiguous(), F32, "bn residual", 2)
+            if residual.shape != (n_out, co):
+                raise ValueError("conv_bn: residual shape mismatch")
+        for t, nm in ((gamma, "gamma"), (beta, "beta")):
+            req(t, F32, "bn " + nm, 1)
+            if t.shape[0] != co:
+                raise ValueError("conv_bn: BatchNorm parameter length != output channels")
+        mean, invstd = _empty((co,), F32, feats), _empty((co,), F32, feats)
+        direct = (transposed and km.fine_bijective) or n_out == 0 or km.n_pairs == 0
+        if direct:
+            x = _conv_forward(feats, kernel, km, transposed)
+            y = torch.empty_like(x)
+            ws_bytes = int(L.ftx_bn_workspace_bytes(n_out, co))
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+            check(L.ftx_bn_train_fwd(ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps),
+                                     n_out, co, int(relu), ptr(y), ptr(mean), ptr(invstd), ptr(ws), ws_bytes, stream()), "ftx_bn_train_fwd")
+        else:
+            gather, pos = (km.pair_out, km.pos_t) if transposed else (km.pair_in, km.pos)
+            tmp = _empty((km.n_pairs, co), F32, feats)
+            x = _empty((n_out, co), F32, feats)
+            y = torch.empty_like(x)
+            nb = int(L.ftx_spconv_reduce_stats_blocks(n_out, co))
+            part = torch.empty((nb, 2, co), dtype=torch.float64, device=feats.device)
+            meta = dict(pairs=km.n_pairs, n_out=n_out, ca=ca, co=co, kvol=kvol)
+            _log_launch("spconv_pairs_gemm", meta, lambda: check(L.ftx_spconv_pairs_gemm(
+                ptr(feats), n_in, ptr(gather), ptr(kernel), 0, ptr(km.koff), km.n_pairs, ca, co, kvol, ptr(tmp), stream()), "ftx_spconv_pairs_gemm"))
+            _log_launch("spconv_reduce", meta, lambda: check(L.ftx_spconv_reduce_stats(
+                ptr(tmp), ptr(pos), n_out, co, kvol, ptr(x), ptr(part), nb, stream()), "ftx_spconv_reduce_stats"))
+            check(L.ftx_bn_train_fwd_partials(ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum),
+                                              float(eps), n_out, co, int(relu), ptr(y), ptr(mean), ptr(invstd), ptr(part), nb, stream()),
+                  "ftx_bn_train_fwd_partials")
+        ctx.save_for_backward(feats, kernel, x, y, gamma, mean, invstd)
+        ctx.km, ctx.transposed, ctx.relu, ctx.has_res = km, transposed, int(relu), residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        feats, kernel, x, y, gamma, mean, invstd = ctx.saved_tensors
+        gy = req(gy.contiguous(), F32, "conv_bn grad", 2)
+        gx, gres, ggamma, gbeta = _bn_backward_launch(gy, x, y, gamma, mean, invstd, ctx.relu, ctx.has_res)
+        g_feats, g_kernel = _conv_backward(feats, kernel, ctx.km, ctx.transposed, gx, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return g_feats, g_kernel, None, None, gres, ggamma, gbeta, None, None, None, None, None
+
+
+def conv_bn_train(feats, kernel, km, transposed, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, residual=None, relu=False):
+    """Conv3d -> BatchNorm(training) (+ residual) (+ ReLU) in one autograd node; see _ConvBNTrain."""
+    return _ConvBNTrain.apply(feats, kernel, km, transposed, residual, gamma, beta, running_mean, running_var, momentum, eps, relu)
 
 
 def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, residual=None, relu=False):

@@ -21,6 +21,8 @@ from .utils import initial_voxelize, initial_voxelize_steps, point_to_voxel, vox
 
 __all__ = ["SPVCNN", "Conv3d", "BatchNorm", "ReLU"]
 
+_FUSE_CONV_BN = os.environ.get("FTX_FUSE_CONV_BN", "1") != "0"
+
 
 class Conv3d(nn.Module):
     """spnn.Conv3d (torchsparse v1.1.0): no bias, kernel (K^3, inc, outc), (inc, outc) when K=1."""
@@ -87,6 +89,26 @@ class ReLU(nn.ReLU):
 
 
 def _conv_bn(conv, bn, x, residual=None, relu=True):
+    """Conv3d -> BatchNorm (-> + residual) (-> ReLU).  In training a k>1 convolution and its BatchNorm run as one autograd node whose
+    reduce pass also produces the batch statistics (functional.conv_bn_train); FTX_FUSE_CONV_BN=0 keeps the two separate nodes."""
+    ks, s = conv.kernel_size, conv.stride
+    if bn.training and _FUSE_CONV_BN and not (ks == 1 and s == 1) and x.F.is_cuda:
+        if not conv.t:
+            km = x.cm.kernel_map(ks, x.s, s)
+            coords, stride = km.out_coords, x.s * s
+        else:
+            original_stride = x.s // s
+            km = x.cm.kernel_maps.get((ks, original_stride, s))
+            if km is None:
+                raise RuntimeError("transposed Conv3d needs the kernel map of the paired strided Conv3d")
+            coords, stride = x.cm.coords[original_stride], original_stride
+        if bn.track_running_stats and bn.num_batches_tracked is not None and not getattr(bn, "_nbt_external", False):
+            bn.num_batches_tracked.add_(1)
+        feats = spf.conv_bn_train(x.F, conv.kernel, km, conv.t, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                  residual=residual, relu=relu)
+        out = x.derive(feats, coords, stride)
+        out.check()
+        return out
     y = conv(x)
     return y.derive(bn.fused(y.F, residual=residual, relu=relu))
 

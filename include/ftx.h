@@ -180,6 +180,12 @@ int ftx_rows_gemm(const float *A, int64_t n, const float *W, int32_t w_transpose
 /* out[r,:] = sum over k (ascending) of tmp[pos[k,r],:] for pos >= 0; out (n, co) fully written. */
 int ftx_spconv_reduce(const float *tmp, const int32_t *pos, int64_t n, int32_t co, int32_t kvol, float *out, void *stream);
 
+/* The reduce pass that also produces the BatchNorm statistics of its output: part (nb, 2, co) float64 per-block partial
+ * (sum, sum of squares), nb = ftx_spconv_reduce_stats_blocks(n, co).  Feed `part` to ftx_bn_train_fwd_partials: the
+ * Conv3d -> BatchNorm pair of every SPVCNN block (models/spvcnn.py:22-35,53-79) then reads the convolution output once. */
+int32_t ftx_spconv_reduce_stats_blocks(int64_t n, int32_t co);
+int ftx_spconv_reduce_stats(const float *tmp, const int32_t *pos, int64_t n, int32_t co, int32_t kvol, float *out, double *part, int32_t nb, void *stream);
+
 /* dW[k] = sum_{p in offset k} A[idx_a[p],:]^T @ G[idx_g[p],:]  -> dW (kvol, ca, cg), fully written.
  * idx_a = idx_g = koff = NULL with kvol = 1: dense rows, dW = A[:n_pairs]^T @ G[:n_pairs]. */
 size_t ftx_spconv_pairs_wgrad_workspace_bytes(int64_t n_pairs, int32_t ca, int32_t cg, int32_t kvol);
@@ -195,6 +201,9 @@ int ftx_spconv_pairs_wgrad(const float *A, int64_t rows_a, const int32_t *idx_a,
  * running_mean / running_var may be NULL (no update).  residual may be NULL. */
 size_t ftx_bn_workspace_bytes(int64_t n, int32_t c);
 int ftx_bn_train_fwd(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean, float *running_var, float momentum, float eps, int64_t n, int32_t c, int32_t relu, float *y, float *save_mean, float *save_invstd, void *workspace, size_t workspace_bytes, void *stream);
+/* Training-mode BatchNorm forward from per-block partial statistics produced by ftx_spconv_reduce_stats (finalize + apply). */
+int ftx_bn_train_fwd_partials(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean, float *running_var, float momentum, float eps, int64_t n, int32_t c, int32_t relu, float *y, float *save_mean, float *save_invstd, const double *part, int32_t nb, void *stream);
+
 /* Eval forward with running statistics. */
 int ftx_bn_eval_fwd(const float *x, const float *residual, const float *gamma, const float *beta, const float *running_mean, const float *running_var, float eps, int64_t n, int32_t c, int32_t relu, float *y, void *stream);
 /* Training backward.  y is the forward output (needed for the ReLU mask when relu!=0).

@@ -199,6 +199,66 @@ def test_sparse_conv_fwd_bwd(env, ca, co, ks, cur, s):
         np.testing.assert_allclose(wtg.grad.cpu().numpy(), wto.grad.numpy(), rtol=1e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("ca,co,ks,cur,s,transposed,res,relu", [(32, 32, 3, 1, 1, False, False, True), (128, 96, 3, 1, 1, False, True, True),
+                                                                 (64, 64, 2, 1, 2, False, False, True), (64, 32, 2, 1, 2, True, False, True),
+                                                                 (4, 32, 3, 1, 1, False, False, False), (384, 256, 3, 2, 1, False, True, True)])
+def test_fused_conv_batchnorm_node_matches_oracle_ops(env, ca, co, ks, cur, s, transposed, res, relu):
+    """Conv3d -> BatchNorm(train) (+residual) (+ReLU) as one node whose reduce pass produces the batch statistics
+    (ftx_spconv_reduce_stats / ftx_bn_train_fwd_partials), against the oracle's conv followed by torch's batch_norm on the CPU:
+    output, running statistics and every gradient."""
+    spf, O = env
+    from fusiontransformer_amd.sparse import CoordinateManager
+    rng = np.random.default_rng(11)
+    c = random_coords(rng, 2500, extent=36, batch=2)
+    c = c[np.argsort(O.sphash(c))]
+    cm = CoordinateManager()
+    cm.coords[1] = dev(c)
+    st = 1
+    while st < cur:
+        cm.kernel_map(2, st, 2)
+        st *= 2
+    km = cm.kernel_map(ks, cur, s)
+    idx_query, _ = O.build_kernel_map(cm.coords[cur].cpu().numpy(), cur, ks, s)
+    n_src, n_dst = (km.n_out, km.n_in) if transposed else (km.n_in, km.n_out)
+    x = rng.standard_normal((n_src, ca)).astype(np.float32)
+    w = (rng.standard_normal((ks ** 3, ca, co)) / np.sqrt(ca * (1 if transposed else ks ** 3))).astype(np.float32)
+    gam, bet = rng.uniform(0.5, 1.5, co).astype(np.float32), rng.standard_normal(co).astype(np.float32)
+    r = rng.standard_normal((n_dst, co)).astype(np.float32) if res else None
+    go = rng.standard_normal((n_dst, co)).astype(np.float32)
+
+    xo, wo = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(w).requires_grad_(True)
+    go_, bo = torch.from_numpy(gam).requires_grad_(True), torch.from_numpy(bet).requires_grad_(True)
+    ro = torch.from_numpy(r).requires_grad_(True) if res else None
+    rm_o, rv_o = torch.zeros(co), torch.ones(co)
+    conv_o = O.sparseconv_op(xo, wo, idx_query, n_dst, transposed)
+    yo = torch.nn.functional.batch_norm(conv_o, rm_o, rv_o, go_, bo, True, 0.1, 1e-5)
+    if res:
+        yo = yo + ro
+    if relu:
+        yo = torch.relu(yo)
+    yo.backward(torch.from_numpy(go))
+
+    xg, wg = dev(x).requires_grad_(True), dev(w).requires_grad_(True)
+    gg, bg = dev(gam).requires_grad_(True), dev(bet).requires_grad_(True)
+    rg = dev(r).requires_grad_(True) if res else None
+    rm_g, rv_g = torch.zeros(co, device="cuda"), torch.ones(co, device="cuda")
+    yg = spf.conv_bn_train(xg, wg, km, transposed, gg, bg, rm_g, rv_g, 0.1, 1e-5, residual=rg, relu=relu)
+    yg.backward(dev(go))
+    np.testing.assert_allclose(yg.detach().cpu().numpy(), yo.detach().numpy(), rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(rm_g.cpu().numpy(), rm_o.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rv_g.cpu().numpy(), rv_o.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xo.grad.numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(wg.grad.cpu().numpy(), wo.grad.numpy(), rtol=2e-3, atol=5e-4)
+    np.testing.assert_allclose(gg.grad.cpu().numpy(), go_.grad.numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(bg.grad.cpu().numpy(), bo.grad.numpy(), rtol=1e-3, atol=1e-3)
+    if res:
+        np.testing.assert_allclose(rg.grad.cpu().numpy(), ro.grad.numpy(), rtol=1e-5, atol=1e-6)
+    # bit-reproducible: the statistics are float64 partials combined in a fixed order
+    yg2 = spf.conv_bn_train(xg.detach(), wg.detach(), km, transposed, gg.detach(), bg.detach(), torch.zeros(co, device="cuda"),
+                            torch.ones(co, device="cuda"), 0.1, 1e-5, residual=None if rg is None else rg.detach(), relu=relu)
+    assert torch.equal(yg2, yg.detach())
+
+
 @pytest.mark.parametrize("n,ca,co", [(5000, 32, 256), (3001, 256, 128), (777, 96, 20), (4096, 128, 96), (130, 4, 32), (1, 384, 256)])
 def test_rows_linear_and_matmul_match_torch(env, n, ca, co):
     spf, O = env
