@@ -13,8 +13,8 @@ bucket is reduced in place with no pack/unpack copies; a bucket's all-reduce is
 issued from the autograd hook of its last gradient and runs on RCCL's stream
 while the rest of the backward continues.  Buckets are launched strictly in
 bucket order on every rank (collectives must match across ranks); the order is
-rebuilt after the first step from the observed gradient-ready order, so later
-steps overlap.  Parameters that never receive a gradient are frozen at model
+rebuilt after the first step from the gradient-ready order rank 0 observed
+(broadcast once, so every rank cuts identical buckets), so later steps overlap.  Parameters that never receive a gradient are frozen at model
 construction instead of using `find_unused_parameters`.  BatchNorm statistics
 stay per replica, as in the reference (no SyncBN anywhere)."""
 from __future__ import annotations
@@ -102,12 +102,28 @@ class GradReducer:
             self.buckets.append(b)
         self.next_to_launch = 0
 
+    def _agree_on_order(self, order):
+        """Every rank must cut the SAME buckets (collectives are matched by issue order), but the gradient-ready order a rank
+        observed in step 0 depends on how its two branch streams and its autograd thread interleaved: rank 0's order is
+        broadcast and adopted by all (one small int64 broadcast, once per job)."""
+        if self.world <= 1:
+            return order
+        index = {p: i for i, p in enumerate(self.params)}
+        ids = torch.tensor([index[p] for p in order], dtype=torch.int64)
+        if dist.get_backend(self.pg) == "nccl":
+            ids = ids.to(self.params[0].device)
+        dist.broadcast(ids, src=0, group=self.pg)
+        ids = ids.cpu().tolist()
+        if sorted(ids) != list(range(len(self.params))):
+            raise RuntimeError("GradReducer: the bucket order received from rank 0 is not a permutation of this rank's parameters")
+        return [self.params[i] for i in ids]
+
     # -- per-step protocol ---------------------------------------------------
     def begin_step(self):
         if self.step_idx == 1 and not self._rebuilt and self.ready_order:
             seen = set(self.ready_order)
             order = self.ready_order + [p for p in reversed(self.params) if p not in seen]
-            self._build(order)
+            self._build(self._agree_on_order(order))
             self._rebuilt = True
         for b in self.buckets:
             b.pending, b.work, b.launched, b.events = len(b.params), None, False, []

@@ -10,6 +10,16 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Multi-process GPU tests (tests/test_dist_gpu.py) take their children from a fork server that is started HERE, before any
+    # test has touched the GPU: a process that has initialised HIP must never fork+exec a new interpreter on this pool, while
+    # forking from the (GPU-free) server involves no exec at all.
+    import multiprocessing as mp
+    try:
+        ctx = mp.get_context("forkserver")
+        from multiprocessing import forkserver
+        forkserver.ensure_running()
+    except (ValueError, RuntimeError, OSError):
+        pass
 
 
 @pytest.fixture(scope="session")
