@@ -147,6 +147,13 @@ class Net2DBillinear(nn.Module):
             self.up[self.middle_feat_block_number] = BilinearModule(self.hidden_channels, self.feat_channels, self.lift_size)
         self.up[self.late_feat_block_number] = BilinearModule(self.hidden_channels, self.feat_channels, self.lift_size)
 
+        if self.middle_feat_block_number and self.middle_feat_block_number != self.late_feat_block_number:
+            # the middle tap's features reach the LiDAR branch detached (middle_fusion.py:102, early_fusion.py:105) and nothing
+            # else consumes them, so this module's parameters never receive a gradient: frozen like the trunk's unused ones
+            # (its BatchNorm running statistics still update in training forwards, as in the reference)
+            for p in self.up[self.middle_feat_block_number].parameters():
+                p.requires_grad_(False)
+
         self.linear = nn.Linear(self.feat_channels, num_classes)
         self.dual_head = dual_head
         if dual_head:

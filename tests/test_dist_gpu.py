@@ -57,6 +57,7 @@ def _dp_worker(rank, world, port, q):
             for n, p in model.named_parameters():
                 if not p.requires_grad:
                     continue
+                assert n in local, "trainable parameter %s received no local gradient" % n
                 g = local[n]
                 parts = [torch.zeros_like(g) for _ in range(world)]
                 dist.all_gather(parts, g)

@@ -47,6 +47,9 @@ def test_build_model_dispatch_and_state_dict_names(kind, cls):
     assert sd[prefix + "up1.1.0.net.0.kernel"].shape == (27, 256 + 128, 256)
     # parameters that never get a gradient are frozen (DDP without find_unused_parameters)
     assert not any(p.requires_grad for p in model.image_backbone.backbone.norm.parameters())
+    if kind in ("middle", "early"):   # the fused tap reaches the LiDAR branch detached: its lift module never gets a gradient
+        assert not any(p.requires_grad for p in model.image_backbone.up["0"].parameters())
+    assert all(p.requires_grad for p in model.image_backbone.up[str(cfg.MODEL.late_feat_block_number)].parameters())
 
 
 def test_build_model_lidar_and_image_only_and_errors():
