@@ -77,13 +77,13 @@ __device__ inline void store_row(float *p, int c, const Row &r) {
 // part[block][4] = { sum w*nll_3d, sum w*nll_2d, sum kl_2d, sum kl_3d }
 __global__ __launch_bounds__(256) void loss_main_kernel(const float *__restrict__ l3, const float *__restrict__ l2, const float *__restrict__ l3b,
                                                         const float *__restrict__ l2b, const int64_t *__restrict__ label,
-                                                        const float *__restrict__ cw, const double *__restrict__ wsum, float lambda_xm,
+                                                        const float *__restrict__ cw, const double *__restrict__ wsum, float ce_scale, float lambda_xm,
                                                         int64_t n, int c, int ignore_index, float *__restrict__ g3, float *__restrict__ g2,
                                                         float *__restrict__ g3b, float *__restrict__ g2b, long long *__restrict__ conf3,
                                                         long long *__restrict__ conf2, double *__restrict__ part) {
   __shared__ double sh[4];
   const bool dual = (l3b != l3);
-  const float invW = (float)(1.0 / wsum[0]);
+  const float invW = ce_scale * (float)(1.0 / wsum[0]);   // d(ce_scale * CE) / d(logits) carries the mix factor
   const float invN = 1.f / (float)n;
   double a_ce3 = 0, a_ce2 = 0, a_kl2 = 0, a_kl3 = 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -171,31 +171,31 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const float *__restrict_
   }
 }
 
-__global__ void loss_finalize_kernel(const double *__restrict__ part, int nb, const double *__restrict__ wsum, float lambda_xm, int64_t n,
-                                     float *__restrict__ losses) {
+__global__ void loss_finalize_kernel(const double *__restrict__ part, int nb, const double *__restrict__ wsum, float ce_scale, float lambda_xm,
+                                     int64_t n, float *__restrict__ losses) {
   if (threadIdx.x != 0) return;
   double s[4] = {0, 0, 0, 0};
   for (int b = 0; b < nb; ++b)
     for (int j = 0; j < 4; ++j) s[j] += part[(int64_t)b * 4 + j];
   const double W = wsum[0];
   const double ce3 = s[0] / W, ce2 = s[1] / W, kl2 = s[2] / (double)n, kl3 = s[3] / (double)n;
-  losses[0] = (float)(ce2 + lambda_xm * kl2);   // loss_2d
-  losses[1] = (float)(ce3 + lambda_xm * kl3);   // loss_3d
+  losses[0] = (float)(ce_scale * ce2 + lambda_xm * kl2);   // loss_2d
+  losses[1] = (float)(ce_scale * ce3 + lambda_xm * kl3);   // loss_3d
 }
 
 extern "C" size_t ftx_fusion_loss_workspace_bytes(void) { return sizeof(double) * (LOSS_BLOCKS * 4 + 2) + 256; }
 
-extern "C" int ftx_fusion_loss(const float *lidar_logit, const float *img_logit, const float *lidar_logit2, const float *img_logit2,
-                               const int64_t *label, const float *class_weights, float lambda_xm, int64_t n, int32_t c, int32_t ignore_index,
+extern "C" int ftx_fusion_loss_mix(const float *lidar_logit, const float *img_logit, const float *lidar_logit2, const float *img_logit2,
+                               const int64_t *label, const float *class_weights, float ce_scale, float lambda_xm, int64_t n, int32_t c, int32_t ignore_index,
                                float *losses, float *grad_lidar, float *grad_img, float *grad_lidar2, float *grad_img2, int64_t *conf3d,
                                int64_t *conf2d, void *workspace, size_t workspace_bytes, void *stream) {
-  FTX_REQUIRE(n >= 1, "ftx_fusion_loss: needs at least one point");
-  FTX_REQUIRE(c >= 4 && c % 4 == 0 && c <= LC_MAX, "ftx_fusion_loss: classes must be a multiple of 4 and <= %d (got %d)", LC_MAX, c);
-  FTX_REQUIRE(lidar_logit && img_logit && label && losses && grad_lidar && grad_img && workspace, "ftx_fusion_loss: null pointer");
+  FTX_REQUIRE(n >= 1, "ftx_fusion_loss_mix: needs at least one point");
+  FTX_REQUIRE(c >= 4 && c % 4 == 0 && c <= LC_MAX, "ftx_fusion_loss_mix: classes must be a multiple of 4 and <= %d (got %d)", LC_MAX, c);
+  FTX_REQUIRE(lidar_logit && img_logit && label && losses && grad_lidar && grad_img && workspace, "ftx_fusion_loss_mix: null pointer");
   const bool dual = lidar_logit2 != nullptr || img_logit2 != nullptr;
-  FTX_REQUIRE(!dual || (lidar_logit2 && img_logit2 && grad_lidar2 && grad_img2), "ftx_fusion_loss: dual head needs both second heads and their gradients");
+  FTX_REQUIRE(!dual || (lidar_logit2 && img_logit2 && grad_lidar2 && grad_img2), "ftx_fusion_loss_mix: dual head needs both second heads and their gradients");
   if (workspace_bytes < ftx_fusion_loss_workspace_bytes()) {
-    set_error("ftx_fusion_loss: workspace too small");
+    set_error("ftx_fusion_loss_mix: workspace too small");
     return FTX_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
@@ -204,8 +204,17 @@ extern "C" int ftx_fusion_loss(const float *lidar_logit, const float *img_logit,
   loss_wsum_kernel<<<1, 1024, 0, st>>>(label, class_weights, n, c, wsum);
   const int nb = (int)(ceil_div(n, 256) < LOSS_BLOCKS ? ceil_div(n, 256) : LOSS_BLOCKS);
   loss_main_kernel<<<nb, 256, 0, st>>>(lidar_logit, img_logit, dual ? lidar_logit2 : lidar_logit, dual ? img_logit2 : img_logit, label, class_weights,
-                                       wsum, lambda_xm, n, c, ignore_index, grad_lidar, grad_img, dual ? grad_lidar2 : grad_lidar,
+                                       wsum, ce_scale, lambda_xm, n, c, ignore_index, grad_lidar, grad_img, dual ? grad_lidar2 : grad_lidar,
                                        dual ? grad_img2 : grad_img, (long long *)conf3d, (long long *)conf2d, part);
-  loss_finalize_kernel<<<1, 64, 0, st>>>(part, nb, wsum, lambda_xm, n, losses);
-  return check_launch("ftx_fusion_loss");
+  loss_finalize_kernel<<<1, 64, 0, st>>>(part, nb, wsum, ce_scale, lambda_xm, n, losses);
+  return check_launch("ftx_fusion_loss_mix");
+}
+
+// The additive mix of modules/SemanticTrainer.py:158-178: CE + lambda * KL.
+extern "C" int ftx_fusion_loss(const float *lidar_logit, const float *img_logit, const float *lidar_logit2, const float *img_logit2,
+                               const int64_t *label, const float *class_weights, float lambda_xm, int64_t n, int32_t c, int32_t ignore_index,
+                               float *losses, float *grad_lidar, float *grad_img, float *grad_lidar2, float *grad_img2, int64_t *conf3d,
+                               int64_t *conf2d, void *workspace, size_t workspace_bytes, void *stream) {
+  return ftx_fusion_loss_mix(lidar_logit, img_logit, lidar_logit2, img_logit2, label, class_weights, 1.f, lambda_xm, n, c, ignore_index, losses,
+                             grad_lidar, grad_img, grad_lidar2, grad_img2, conf3d, conf2d, workspace, workspace_bytes, stream);
 }

@@ -810,7 +810,7 @@ def sample_down(img, conv_w, conv_b, gamma, beta, running_mean, running_var, mom
 # ---------------------------------------------------------------- fused losses + metric
 class _FusionLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, l3, l2, l3b, l2b, label, class_weights, lambda_xm, conf3d, conf2d, ignore_index):
+    def forward(ctx, l3, l2, l3b, l2b, label, class_weights, lambda_xm, conf3d, conf2d, ignore_index, ce_scale=1.0):
         L = _lib.load()
         l3 = req(l3.contiguous(), F32, "loss lidar_seg_logit", 2)
         l2 = req(l2.contiguous(), F32, "loss img_seg_logit", 2)
@@ -828,9 +828,9 @@ class _FusionLoss(torch.autograd.Function):
         g2b = torch.empty_like(l2) if dual else None
         ws_bytes = int(L.ftx_fusion_loss_workspace_bytes())
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=l3.device)
-        check(L.ftx_fusion_loss(ptr(l3), ptr(l2), ptr(l3b), ptr(l2b), ptr(label), ptr(class_weights), float(lambda_xm), n, c, int(ignore_index),
-                                ptr(losses), ptr(g3), ptr(g2), ptr(g3b), ptr(g2b), ptr(conf3d), ptr(conf2d), ptr(ws), ws_bytes, stream()),
-              "ftx_fusion_loss")
+        check(L.ftx_fusion_loss_mix(ptr(l3), ptr(l2), ptr(l3b), ptr(l2b), ptr(label), ptr(class_weights), float(ce_scale), float(lambda_xm), n, c,
+                                    int(ignore_index), ptr(losses), ptr(g3), ptr(g2), ptr(g3b), ptr(g2b), ptr(conf3d), ptr(conf2d), ptr(ws), ws_bytes,
+                                    stream()), "ftx_fusion_loss_mix")
         ctx.save_for_backward(g3, g2, g3b, g2b) if dual else ctx.save_for_backward(g3, g2)
         ctx.dual = dual
         return losses
@@ -840,18 +840,23 @@ class _FusionLoss(torch.autograd.Function):
         # the kernel produced d(loss_2d + loss_3d); loss_2d depends only on (l2, l2b), loss_3d only on (l3, l3b)
         if ctx.dual:
             g3, g2, g3b, g2b = ctx.saved_tensors
-            return g3 * g[1], g2 * g[0], g3b * g[1], g2b * g[0], None, None, None, None, None, None
+            return g3 * g[1], g2 * g[0], g3b * g[1], g2b * g[0], None, None, None, None, None, None, None
         g3, g2 = ctx.saved_tensors
         if not torch.equal(g[0], g[1]):
             raise RuntimeError("fusion_loss (single head): loss_2d and loss_3d share logits; call backward on their sum")
-        return g3 * g[0], g2 * g[0], None, None, None, None, None, None, None, None
+        return g3 * g[0], g2 * g[0], None, None, None, None, None, None, None, None, None
 
 
-def fusion_loss(preds, seg_label, class_weights, lambda_xm, dual_head, conf3d=None, conf2d=None, ignore_index=0):
-    """(loss_2d, loss_3d) of SemanticTrainer.py:158-178 in one fused pass; conf3d / conf2d (C,C) int64
-    tensors, when given, accumulate the SegIoU confusion matrices of models/metric.py:37-58."""
+def fusion_loss(preds, seg_label, class_weights, lambda_xm, dual_head, conf3d=None, conf2d=None, ignore_index=0, mix="additive"):
+    """(loss_2d, loss_3d) in one fused pass; conf3d / conf2d (C,C) int64 tensors, when given, accumulate the SegIoU confusion
+    matrices of models/metric.py:37-58.  mix="additive": CE + lambda*KL (SemanticTrainer.py:158-178); mix="torchpack":
+    (1-lambda)*CE + lambda*KL when lambda > 0 (modules/SemanticTorchpackTrainer.py:70-106)."""
+    if mix not in ("additive", "torchpack"):
+        raise ValueError("fusion_loss: mix must be 'additive' or 'torchpack'")
+    ce_scale = (1.0 - float(lambda_xm)) if (mix == "torchpack" and lambda_xm > 0) else 1.0
     out = _FusionLoss.apply(preds["lidar_seg_logit"], preds["img_seg_logit"], preds["lidar_seg_logit2"] if dual_head else None,
-                            preds["img_seg_logit2"] if dual_head else None, seg_label.long(), class_weights, lambda_xm, conf3d, conf2d, ignore_index)
+                            preds["img_seg_logit2"] if dual_head else None, seg_label.long(), class_weights, lambda_xm, conf3d, conf2d, ignore_index,
+                            ce_scale)
     return out[0], out[1]
 
 

@@ -14,8 +14,16 @@ import torch
 import torch.nn.functional as F
 
 
-def fusion_losses(preds, seg_label, class_weights, lambda_xm, dual_head):
-    """(loss_2d, loss_3d) exactly as SemanticTrainer.py:158-178."""
+def default_class_weights(num_classes, device=None):
+    """The torchpack trainer's fallback when cfg.TRAIN.CLASS_WEIGHTS is empty (SemanticTorchpackTrainer.py:28-32): ones, class 0 ignored."""
+    w = torch.ones(num_classes, device=device)
+    w[0] = 0
+    return w
+
+
+def fusion_losses(preds, seg_label, class_weights, lambda_xm, dual_head, mix="additive"):
+    """(loss_2d, loss_3d) exactly as SemanticTrainer.py:158-178 (mix="additive") or as the torchpack / DDP trainer's
+    calc_loss, SemanticTorchpackTrainer.py:70-106 (mix="torchpack": (1-lambda)*CE + lambda*KL)."""
     seg_label = seg_label.long()
     loss_3d = F.cross_entropy(preds["lidar_seg_logit"], seg_label, weight=class_weights)
     loss_2d = F.cross_entropy(preds["img_seg_logit"], seg_label, weight=class_weights)
@@ -26,8 +34,12 @@ def fusion_losses(preds, seg_label, class_weights, lambda_xm, dual_head):
                               reduction="none").sum(1).mean()
         xm_loss_3d = F.kl_div(F.log_softmax(seg_logit_3d, dim=1), F.softmax(preds["img_seg_logit"].detach(), dim=1),
                               reduction="none").sum(1).mean()
-        loss_2d = loss_2d + lambda_xm * xm_loss_2d
-        loss_3d = loss_3d + lambda_xm * xm_loss_3d
+        if mix == "torchpack":
+            loss_2d = (1 - lambda_xm) * loss_2d + lambda_xm * xm_loss_2d
+            loss_3d = (1 - lambda_xm) * loss_3d + lambda_xm * xm_loss_3d
+        else:
+            loss_2d = loss_2d + lambda_xm * xm_loss_2d
+            loss_3d = loss_3d + lambda_xm * xm_loss_3d
     return loss_2d, loss_3d
 
 
@@ -41,12 +53,18 @@ def build_optimizer(cfg, model):
 
 
 class TrainStep:
-    def __init__(self, cfg, model, optimizer=None, metrics=None, grad_reducer=None):
-        self.cfg, self.model = cfg, model
+    def __init__(self, cfg, model, optimizer=None, metrics=None, grad_reducer=None, loss_mix="additive"):
+        """loss_mix="additive": SemanticTrainer.train_step (the single-process trainer); "torchpack": the DDP trainer's mix and its
+        default class weights (SemanticTorchpackTrainer.py:28-32,70-106) -- the one BASELINE configs[3] / [4] follow."""
+        if loss_mix not in ("additive", "torchpack"):
+            raise ValueError("loss_mix must be 'additive' or 'torchpack'")
+        self.cfg, self.model, self.loss_mix = cfg, model, loss_mix
         self.optimizer = optimizer if optimizer is not None else build_optimizer(cfg, model)
         dev = next(model.parameters()).device
         cw = cfg.TRAIN.CLASS_WEIGHTS
         self.class_weights = torch.tensor(cw, dtype=torch.float32, device=dev) if len(cw) > 0 else None
+        if self.class_weights is None and loss_mix == "torchpack":
+            self.class_weights = default_class_weights(int(cfg.MODEL.NUM_CLASSES), dev)
         self.lambda_xm = float(cfg.TRAIN.FusionTransformer.lambda_xm)
         self.dual_head = bool(cfg.MODEL.DUAL_HEAD)
         self.metrics = metrics or ()
@@ -70,9 +88,9 @@ class TrainStep:
                 conf["3d" if "3d" in m.name else "2d"] = m.mat
             from . import functional as spf
             loss_2d, loss_3d = spf.fusion_loss(preds, data_batch["seg_label"], self.class_weights, self.lambda_xm, self.dual_head,
-                                               conf3d=conf["3d"], conf2d=conf["2d"])
+                                               conf3d=conf["3d"], conf2d=conf["2d"], mix=self.loss_mix)
         else:
-            loss_2d, loss_3d = fusion_losses(preds, data_batch["seg_label"], self.class_weights, self.lambda_xm, self.dual_head)
+            loss_2d, loss_3d = fusion_losses(preds, data_batch["seg_label"], self.class_weights, self.lambda_xm, self.dual_head, self.loss_mix)
             with torch.no_grad():
                 for m in self.metrics:
                     m.update_dict(preds, data_batch)

@@ -228,6 +228,9 @@ int ftx_attn_bwd(const float *qkv, const float *out, const float *grad_out, cons
  * grad_* (n,c) receive d(loss_2d + loss_3d)/d(logits), fully written.  conf3d / conf2d (c,c) int64 are
  * ACCUMULATED: conf[label, argmax] += 1 for label != ignore_index (NULL = no metric).  c % 4 == 0, c <= 32. */
 size_t ftx_fusion_loss_workspace_bytes(void);
+/* The same with an explicit mix: loss = ce_scale * CE_w + lambda * KL.  ce_scale = 1 is the additive form of SemanticTrainer.py:158-178
+ * (ftx_fusion_loss); ce_scale = 1 - lambda is the torchpack / DDP trainer's mix (modules/SemanticTorchpackTrainer.py:70-106). */
+int ftx_fusion_loss_mix(const float *lidar_logit, const float *img_logit, const float *lidar_logit2, const float *img_logit2, const int64_t *label, const float *class_weights, float ce_scale, float lambda_xm, int64_t n, int32_t c, int32_t ignore_index, float *losses, float *grad_lidar, float *grad_img, float *grad_lidar2, float *grad_img2, int64_t *conf3d, int64_t *conf2d, void *workspace, size_t workspace_bytes, void *stream);
 int ftx_fusion_loss(const float *lidar_logit, const float *img_logit, const float *lidar_logit2, const float *img_logit2, const int64_t *label, const float *class_weights, float lambda_xm, int64_t n, int32_t c, int32_t ignore_index, float *losses, float *grad_lidar, float *grad_img, float *grad_lidar2, float *grad_img2, int64_t *conf3d, int64_t *conf2d, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- evaluation scatter-back: data/utils/validate.py:62-120 + data/utils/evaluate.py:12-26 ----

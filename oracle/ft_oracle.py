@@ -732,7 +732,8 @@ def build_model(model_cfg):
 # --------------------------------------------------------------------------
 # 9. losses (modules/SemanticTrainer.py:158-178) and SegIoU (models/metric.py:37-68)
 # --------------------------------------------------------------------------
-def fusion_losses(preds, seg_label, class_weights, lambda_xm, dual_head):
+def fusion_losses(preds, seg_label, class_weights, lambda_xm, dual_head, mix="additive"):
+    """mix="additive": modules/SemanticTrainer.py:158-178; mix="torchpack": modules/SemanticTorchpackTrainer.py:70-106."""
     loss_3d = F.cross_entropy(preds["lidar_seg_logit"], seg_label.long(), weight=class_weights)
     loss_2d = F.cross_entropy(preds["img_seg_logit"], seg_label.long(), weight=class_weights)
     if lambda_xm > 0:
@@ -740,8 +741,12 @@ def fusion_losses(preds, seg_label, class_weights, lambda_xm, dual_head):
         l3 = preds["lidar_seg_logit2"] if dual_head else preds["lidar_seg_logit"]
         xm2 = F.kl_div(F.log_softmax(l2, dim=1), F.softmax(preds["lidar_seg_logit"].detach(), dim=1), reduction="none").sum(1).mean()
         xm3 = F.kl_div(F.log_softmax(l3, dim=1), F.softmax(preds["img_seg_logit"].detach(), dim=1), reduction="none").sum(1).mean()
-        loss_2d = loss_2d + lambda_xm * xm2
-        loss_3d = loss_3d + lambda_xm * xm3
+        if mix == "torchpack":
+            loss_2d = (1 - lambda_xm) * loss_2d + lambda_xm * xm2
+            loss_3d = (1 - lambda_xm) * loss_3d + lambda_xm * xm3
+        else:
+            loss_2d = loss_2d + lambda_xm * xm2
+            loss_3d = loss_3d + lambda_xm * xm3
     return loss_2d, loss_3d
 
 

@@ -16,6 +16,8 @@ What is pinned, and by which reference code:
                        modules/SemanticTrainer.py:158-178 (that method cannot be called: it
                        lives in a class that needs wandb/torchsparse), and the reference's
                        SegIoU (models/metric.py:26-82) run on seeded logits.
+  losses_torchpack.npz the torchpack / DDP trainer's loss mix and default class weights, statements of
+                       modules/SemanticTorchpackTrainer.py:28-32,70-106, on the logits of losses_metric.npz.
   voxel_coords.npz     reference augment_and_scale_3d (data/utils/augmentation_3d.py:4-53) and
                        the int cast / range mask of semantic_kitti_dataloader.py:216-225.
   projection.npz       reference DummyDataset.read_calib / select_points_in_frustum and the
@@ -122,6 +124,35 @@ def losses_metric():
                         iou3d=m3.iou.numpy(), iou2d=m2.iou.numpy(), **{k: v.numpy() for k, v in preds.items()})
 
 
+def losses_torchpack():
+    """Statements of modules/SemanticTorchpackTrainer.py:28-32 (class weights) and :70-106 (calc_loss, USE_FUSION branch); the method
+    itself lives in a torchpack Trainer subclass that cannot be imported here.  Same seeded logits as losses_metric."""
+    import torch.nn.functional as F
+    g = np.load(os.path.join(OUT, "losses_metric.npz"))
+    preds = {k: torch.from_numpy(g[k]) for k in ("lidar_seg_logit", "img_seg_logit", "lidar_seg_logit2", "img_seg_logit2")}
+    label = torch.from_numpy(g["label"])
+    save = {}
+    for tag, weights, lam, dual in (("cfgw", torch.from_numpy(g["class_weights"]), 0.1, True), ("defw", None, 0.1, True),
+                                    ("single", torch.from_numpy(g["class_weights"]), 0.25, False), ("nolam", None, 0.0, True)):
+        if weights is not None:                       # SemanticTorchpackTrainer.py:28-29
+            class_weights = weights
+        else:                                         # :30-32
+            class_weights = torch.ones(20)
+            class_weights[0] = 0
+        loss_3d = F.cross_entropy(preds['lidar_seg_logit'], label.long(), weight=class_weights)
+        loss_2d = F.cross_entropy(preds['img_seg_logit'], label.long(), weight=class_weights)
+        if lam > 0:
+            seg_logit_2d = preds['img_seg_logit2'] if dual else preds['img_seg_logit']
+            seg_logit_3d = preds['lidar_seg_logit2'] if dual else preds['lidar_seg_logit']
+            xm_loss_2d = F.kl_div(F.log_softmax(seg_logit_2d, dim=1), F.softmax(preds['lidar_seg_logit'].detach(), dim=1), reduction='none').sum(1).mean()
+            xm_loss_3d = F.kl_div(F.log_softmax(seg_logit_3d, dim=1), F.softmax(preds['img_seg_logit'].detach(), dim=1), reduction='none').sum(1).mean()
+            loss_2d = (1 - lam) * loss_2d + (lam) * xm_loss_2d
+            loss_3d = (1 - lam) * loss_3d + (lam) * xm_loss_3d
+        save.update({tag + "_loss_2d": loss_2d.numpy(), tag + "_loss_3d": loss_3d.numpy(), tag + "_lambda": lam, tag + "_dual": dual,
+                     tag + "_weights": class_weights.numpy()})
+    np.savez_compressed(os.path.join(OUT, "losses_torchpack.npz"), **save)
+
+
 def voxel_coords():
     from FusionTransformer.data.utils.augmentation_3d import augment_and_scale_3d
     rng = np.random.default_rng(2)
@@ -222,6 +253,7 @@ if __name__ == "__main__":
     upsample_index()
     bilinear_lift()
     losses_metric()
+    losses_torchpack()
     voxel_coords()
     projection()
     eval_scatter_back()

@@ -69,6 +69,23 @@ def test_losses_and_seg_iou_match_reference():
     np.testing.assert_allclose(m2.iou.numpy(), g["iou2d"], rtol=1e-6, equal_nan=True)
 
 
+def test_torchpack_loss_mix_matches_reference_statements():
+    """(1-lambda)*CE + lambda*KL and the ones-with-w[0]=0 default class weights of the DDP trainer
+    (modules/SemanticTorchpackTrainer.py:28-32,70-106): oracle and the host-side mirror against the reference's statements."""
+    from oracle import ft_oracle as O
+    from fusiontransformer_amd.trainer import default_class_weights, fusion_losses
+    g, t = load("losses_metric.npz"), load("losses_torchpack.npz")
+    preds = {k: torch.from_numpy(g[k]) for k in ("lidar_seg_logit", "img_seg_logit", "lidar_seg_logit2", "img_seg_logit2")}
+    label = torch.from_numpy(g["label"])
+    for tag in ("cfgw", "defw", "single", "nolam"):
+        w, lam, dual = torch.from_numpy(t[tag + "_weights"]), float(t[tag + "_lambda"]), bool(t[tag + "_dual"])
+        if tag in ("defw", "nolam"):
+            assert torch.equal(w, default_class_weights(20))
+        for fn in (O.fusion_losses, fusion_losses):
+            l2, l3 = fn(preds, label, w, lam, dual, mix="torchpack")
+            assert abs(l2.item() - float(t[tag + "_loss_2d"])) < 1e-6 and abs(l3.item() - float(t[tag + "_loss_3d"])) < 1e-6, (tag, fn)
+
+
 def test_voxel_coordinates_match_reference_augment_and_scale():
     from fusiontransformer_amd.data.synth import scale_points_to_voxels
     g = load("voxel_coords.npz")
@@ -158,6 +175,31 @@ def test_fused_loss_kernel_matches_reference_goldens():
     r2, r3 = fusion_losses({k: v.cpu() for k, v in preds.items()}, label.cpu(), None, 0.0, True)
     assert abs(l2.item() - r2.item()) < 2e-6 and abs(l3.item() - r3.item()) < 2e-6
     assert np.array_equal(c3.cpu().numpy(), 2 * g["mat3d"])
+
+
+@pytest.mark.gpu
+def test_fused_loss_kernel_torchpack_mix_matches_reference_goldens():
+    """ftx_fusion_loss_mix with ce_scale = 1 - lambda against the torchpack trainer's statements (values) and autograd through
+    them (gradients), for configured / default class weights, dual / single head, lambda = 0."""
+    from fusiontransformer_amd import functional as spf
+    from fusiontransformer_amd.trainer import fusion_losses
+    g, t = load("losses_metric.npz"), load("losses_torchpack.npz")
+    names = ("lidar_seg_logit", "img_seg_logit", "lidar_seg_logit2", "img_seg_logit2")
+    label = torch.from_numpy(g["label"]).cuda()
+    for tag in ("cfgw", "defw", "single", "nolam"):
+        w, lam, dual = torch.from_numpy(t[tag + "_weights"]), float(t[tag + "_lambda"]), bool(t[tag + "_dual"])
+        preds = {k: torch.from_numpy(g[k]).cuda().requires_grad_(True) for k in names}
+        ref = {k: torch.from_numpy(g[k]).double().requires_grad_(True) for k in names}
+        l2, l3 = spf.fusion_loss(preds, label, w.cuda(), lam, dual, mix="torchpack")
+        r2, r3 = fusion_losses(ref, label.cpu(), w.double(), lam, dual, mix="torchpack")
+        (l2 + l3).backward()
+        (r2 + r3).backward()
+        assert abs(l2.item() - float(t[tag + "_loss_2d"])) < 2e-6 and abs(l3.item() - float(t[tag + "_loss_3d"])) < 2e-6, tag
+        for k in names:
+            if ref[k].grad is None:
+                assert preds[k].grad is None or preds[k].grad.abs().max().item() == 0, (tag, k)
+                continue
+            np.testing.assert_allclose(preds[k].grad.cpu().numpy(), ref[k].grad.numpy(), rtol=1e-4, atol=1e-9)
 
 
 @pytest.mark.gpu
