@@ -249,6 +249,33 @@ extern "C" int ftx_unique_sorted(const int64_t *keys, int64_t n, int64_t *uniq, 
   return check_launch("ftx_unique_sorted");
 }
 
+// rank[i] = position of queries[i] in sorted[0 .. *n_sorted) (ascending, unique), or -1 when absent: with `sorted` = the output of
+// ftx_unique_sorted this is numpy.unique's `return_inverse` (torchsparse sparse_quantize(..., return_invs=True),
+// data/semantic_kitti/semantic_kitti_dataloader.py:231) -- the count stays on the device, nothing is read back.
+__global__ void sorted_rank_kernel(const int64_t *__restrict__ sorted, const int32_t *__restrict__ n_sorted, const int64_t *__restrict__ q,
+                                   int64_t nq, int64_t cap, int32_t *__restrict__ rank) {
+  int64_t m = *n_sorted;
+  if (m > cap) m = cap;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nq; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t key = q[i];
+    int64_t lo = 0, hi = m;
+    while (lo < hi) {
+      int64_t mid = (lo + hi) >> 1;
+      if (sorted[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    rank[i] = (lo < m && sorted[lo] == key) ? (int32_t)lo : -1;
+  }
+}
+
+extern "C" int ftx_sorted_rank(const int64_t *sorted, const int32_t *n_sorted, int64_t capacity, const int64_t *queries, int64_t nq, int32_t *rank,
+                               void *stream) {
+  FTX_REQUIRE(nq >= 0 && capacity >= 0 && capacity < 0x7fffffff, "ftx_sorted_rank: bad size");
+  if (nq == 0) return FTX_OK;
+  FTX_REQUIRE(sorted && n_sorted && queries && rank, "ftx_sorted_rank: null pointer");
+  sorted_rank_kernel<<<grid_for(nq, 256), 256, 0, (hipStream_t)stream>>>(sorted, n_sorted, queries, nq, capacity, rank);
+  return check_launch("ftx_sorted_rank");
+}
+
 // ---------------------------------------------------------------- downsample / gather of coordinate rows
 __device__ inline int floor_div(int a, int b) {
   int q = a / b;

@@ -75,11 +75,18 @@ def validate_batch(preds, data_batch, class_labels, evaluator_3d=None, evaluator
     label ids) when `want_preds`."""
     l3, l2 = preds.get("lidar_seg_logit"), preds.get("img_seg_logit")
     ref = l3 if l3 is not None else l2
-    pts = [int(np.sum(np.asarray(p))) for p in data_batch["sparse_orig_points_idx"]]
-    for p, idx in zip(pts, data_batch["sparse_orig_points_idx"]):
-        assert p == len(idx), "every voxel must carry a prediction (validate.py:87)"
-    inverse = pack_inverse_maps(data_batch["inverse_map"], pts, ref.device)
-    gt = torch.from_numpy(np.concatenate([np.asarray(g, dtype=np.int32) for g in data_batch["orig_seg_label"]])).to(ref.device, non_blocking=True)
+    if "inverse_map_packed" in data_batch:
+        # batch built on the device (data/voxelize.collate_device): the maps are already packed, nothing crosses PCIe
+        inverse = data_batch["inverse_map_packed"]
+        gt = data_batch["orig_seg_label_packed"]
+        if inverse.shape[0] != gt.shape[0]:
+            raise ValueError("validate_batch: packed inverse map and labels differ in length")
+    else:
+        pts = [int(np.sum(np.asarray(p))) for p in data_batch["sparse_orig_points_idx"]]
+        for p, idx in zip(pts, data_batch["sparse_orig_points_idx"]):
+            assert p == len(idx), "every voxel must carry a prediction (validate.py:87)"
+        inverse = pack_inverse_maps(data_batch["inverse_map"], pts, ref.device)
+        gt = torch.from_numpy(np.concatenate([np.asarray(g, dtype=np.int32) for g in data_batch["orig_seg_label"]])).to(ref.device, non_blocking=True)
     labels = torch.as_tensor(np.asarray(class_labels, dtype=np.int32))
     p3, p2, pe, bad = spf.eval_scatter_back(l3, l2, inverse, gt, labels,
                                             conf3d=None if evaluator_3d is None else evaluator_3d.mat,

@@ -102,6 +102,18 @@ def unique_sorted(keys: torch.Tensor):
     return uniq, first, cnt
 
 
+def sorted_rank(sorted_keys: torch.Tensor, n_sorted: torch.Tensor, queries: torch.Tensor) -> torch.Tensor:
+    """Position of every query in sorted_keys[:n_sorted] (ascending, unique), -1 when absent; n_sorted is a (1,) int32 DEVICE tensor,
+    so `unique_sorted` + `sorted_rank` give numpy.unique(return_index, return_inverse) without a host read."""
+    L = _lib.load()
+    req(sorted_keys, I64, "sorted_rank sorted", 1)
+    req(n_sorted, I32, "sorted_rank n_sorted", 1)
+    req(queries, I64, "sorted_rank queries", 1)
+    rank = _empty((queries.shape[0],), I32, queries)
+    check(L.ftx_sorted_rank(ptr(sorted_keys), ptr(n_sorted), sorted_keys.shape[0], ptr(queries), queries.shape[0], ptr(rank), stream()), "ftx_sorted_rank")
+    return rank
+
+
 def downsample_coords(coords: torch.Tensor, ratio: int) -> torch.Tensor:
     L = _lib.load()
     req(coords, I32, "downsample coords", 2)

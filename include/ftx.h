@@ -67,6 +67,10 @@ int ftx_count(const int32_t *idx, int64_t n, int32_t *counts, int64_t m, void *s
  * Rows past n_unique are unspecified. */
 size_t ftx_unique_workspace_bytes(int64_t n);
 int ftx_unique_sorted(const int64_t *keys, int64_t n, int64_t *uniq, int32_t *first_index, int32_t *n_unique, void *workspace, size_t workspace_bytes, void *stream);
+/* rank[i] = position of queries[i] in sorted[0 .. min(*n_sorted, capacity)) (ascending, unique; the count is read ON THE DEVICE), -1 when
+ * absent.  On the output of ftx_unique_sorted this is numpy.unique's return_inverse, i.e. the inverse map of torchsparse
+ * sparse_quantize(..., return_invs=True) (data/semantic_kitti/semantic_kitti_dataloader.py:231). */
+int ftx_sorted_rank(const int64_t *sorted, const int32_t *n_sorted, int64_t capacity, const int64_t *queries, int64_t nq, int32_t *rank, void *stream);
 
 /* torchsparse spdownsample coordinate rule: floor(c / ratio) * ratio on x,y,z, b kept.
  * coords (n,4) int32 -> out (n,4) int32.  (inside spnn.Conv3d(stride=2): models/spvcnn.py:105,111,117,123) */
