@@ -341,7 +341,7 @@ extern "C" int ftx_kernel_map_build(const int32_t *out_coords, int64_t n_out, co
 }
 
 // ---------------------------------------------------------------- trilinear weights
-// float64 arithmetic as upstream calc_ti_weights; corner order (bx,by,bz) with z fastest
+// float32 arithmetic in upstream calc_ti_weights' operation order; corner order (bx,by,bz) with z fastest
 // (= KernelRegion(2, s, 1) offsets).
 __global__ void trilinear_kernel(const float4 *__restrict__ pc, const int32_t *__restrict__ idx, int64_t n, int scale,
                                  float *__restrict__ w) {
@@ -355,23 +355,25 @@ __global__ void trilinear_kernel(const float4 *__restrict__ pc, const int32_t *_
       fx = floorf(p.x); fy = floorf(p.y); fz = floorf(p.z);
     }
     float cx = fx + s, cy = fy + s, cz = fz + s;
-    double lo[3] = {(double)p.x - (double)fx, (double)p.y - (double)fy, (double)p.z - (double)fz};
-    double hi[3] = {(double)cx - (double)p.x, (double)cy - (double)p.y, (double)cz - (double)p.z};
-    double ws[8];
-    double sum = 0.0;
-    const double inv = (scale != 1) ? (double)scale * (double)scale * (double)scale : 1.0;
+    // float32 throughout, in upstream's operation order (torchsparse calc_ti_weights works in the dtype of `pc`, float32):
+    // three-factor product, division by scale^3, zero for absent corners, sum of the 8, division by (sum + 1e-8)
+    const float lo[3] = {p.x - fx, p.y - fy, p.z - fz};
+    const float hi[3] = {cx - p.x, cy - p.y, cz - p.z};
+    float ws[8];
+    float sum = 0.f;
+    const float inv = s * s * s;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       int bx = (c >> 2) & 1, by = (c >> 1) & 1, bz = c & 1;
-      double v = ((bx ? lo[0] : hi[0]) * (by ? lo[1] : hi[1])) * (bz ? lo[2] : hi[2]);
+      float v = ((bx ? lo[0] : hi[0]) * (by ? lo[1] : hi[1])) * (bz ? lo[2] : hi[2]);
       if (scale != 1) v = v / inv;
-      if (idx[i * 8 + c] < 0) v = 0.0;
+      if (idx[i * 8 + c] < 0) v = 0.f;
       ws[c] = v;
       sum += v;
     }
-    const double den = sum + 1e-8;
+    const float den = sum + 1e-8f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) w[i * 8 + c] = (float)(ws[c] / den);
+    for (int c = 0; c < 8; ++c) w[i * 8 + c] = ws[c] / den;
   }
 }
 

@@ -17,8 +17,9 @@ class SegIoU(object):
             seg_logit = preds["img_seg_logit"]
         seg_label = labels["seg_label"].detach().long().to(seg_logit.device)
         pred_label = seg_logit.detach().argmax(1)
-        mask = seg_label != self.ignore_index
         n = self.num_classes
+        # points whose label is the ignored class, or outside [0, n) (e.g. -100), are not counted -- as ftx_fusion_loss does
+        mask = (seg_label != self.ignore_index) & (seg_label >= 0) & (seg_label < n)
         with torch.no_grad():
             if self.mat is None:
                 self.mat = seg_label.new_zeros((n, n))

@@ -122,29 +122,31 @@ def spvoxelize(feats, idx, counts):
 def calc_ti_weights(pc, idx_query, scale=1):
     """Trilinear weights, (8,N) float32 (models/utils.py:81-82).
 
-    Corner order follows kernel_offsets(2, scale) (z fastest); computed in
-    float64, zeroed where the neighbour is absent, renormalised by sum+1e-8."""
+    Corner order follows kernel_offsets(2, scale) (z fastest).  float32 throughout, in the operation order of
+    torchsparse v1.1.0 calc_ti_weights (it works in the dtype of `pc`): three-factor product, / scale**3, zero where
+    the neighbour is absent, / (sum + 1e-8)."""
     pc = np.asarray(pc, dtype=np.float32)[:, :3]
+    s32 = np.float32(scale)
     if scale != 1:
-        pc_floor = np.floor(pc / np.float32(scale)) * np.float32(scale)
+        pc_floor = np.floor(pc / s32) * s32
     else:
         pc_floor = np.floor(pc)
-    pc_ceil = pc_floor + np.float32(scale)
-    g = pc.astype(np.float64)
-    fl = pc_floor.astype(np.float64)
-    ce = pc_ceil.astype(np.float64)
-    lo = g - fl  # weight towards the +offset corner
-    hi = ce - g  # weight towards the 0 corner
+    pc_ceil = pc_floor + s32
+    lo = pc - pc_floor   # weight towards the +offset corner
+    hi = pc_ceil - pc    # weight towards the 0 corner
     ws = []
     for bx in (0, 1):
         for by in (0, 1):
             for bz in (0, 1):
-                ws.append((lo[:, 0] if bx else hi[:, 0]) * (lo[:, 1] if by else hi[:, 1]) * (lo[:, 2] if bz else hi[:, 2]))
-    w = np.stack(ws, 0)
+                ws.append(((lo[:, 0] if bx else hi[:, 0]) * (lo[:, 1] if by else hi[:, 1])) * (lo[:, 2] if bz else hi[:, 2]))
+    w = np.stack(ws, 0).astype(np.float32)
     if scale != 1:
-        w = w / float(scale) ** 3
+        w = w / (s32 * s32 * s32)
     w[np.asarray(idx_query) == -1] = 0
-    w = w / (w.sum(0) + 1e-8)
+    tot = np.zeros(w.shape[1], dtype=np.float32)
+    for c in range(8):
+        tot = tot + w[c]
+    w = w / (tot + np.float32(1e-8))
     return w.astype(np.float32)
 
 
