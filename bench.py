@@ -48,16 +48,31 @@ def build_inputs(cfg, batch, shape, rank, device, cycle=0):
 
 
 def spconv_roofline(log, workload=None):
-    """Algorithmic bytes / HIP-event time over the sparse-conv launches of one timed step.
+    """Algorithmic bytes / HIP-event time over the sparse-conv launches of one timed step (the dominant hand-written kernel group),
+    plus the same accounting for the other hand-written groups (BatchNorm: HBM, attention: MFMA) under "other_kernel_groups".
 
     Unit = one (in,out) pair: 4*(ca+co) bytes (gather ca floats + write co floats), plus
     the kernel weights 4*kvol*ca*co read once per convolution.  A convolution is two launches
-    (pair gather-GEMM, ordered reduce) or one (weight gradient); the bytes are attributed to the
-    GEMM / wgrad launch, the reduce launch adds time only."""
+    (pair gather-GEMM, ordered reduce), or one (weight gradient; bijective maps, whose GEMM epilogue writes the output
+    itself); the bytes are attributed to the GEMM / wgrad launch, the reduce launch adds time only."""
     tot_bytes = tot_ms = tot_flops = 0.0
     per_kind = {}
+    bn = {"launches": 0, "ms": 0.0, "bytes": 0.0}
+    attn = {"launches": 0, "ms": 0.0, "flops": 0.0}
+    n_sp = 0
     for kind, e0, e1, m in log:
         ms = e0.elapsed_time(e1)
+        if kind.startswith("bn_"):
+            bn["launches"] += 1
+            bn["ms"] += ms
+            bn["bytes"] += 4.0 * m["n"] * m["c"] * (m["reads"] + m["writes"])
+            continue
+        if kind.startswith("attn_"):
+            attn["launches"] += 1
+            attn["ms"] += ms
+            attn["flops"] += m["products"] * 2.0 * m["b"] * m["h"] * m["t"] * m["t"] * m["d"]
+            continue
+        n_sp += 1
         nbytes = flops = 0.0
         if kind != "spconv_reduce":
             nbytes = 4.0 * m["pairs"] * (m["ca"] + m["co"]) + 4.0 * m["kvol"] * m["ca"] * m["co"]
@@ -75,24 +90,43 @@ def spconv_roofline(log, workload=None):
     achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
     n_conv = sum(v[0] for k, v in per_kind.items() if k != "spconv_reduce")
     traffic, traffic_note = None, None
-    try:  # HBM bytes of these kernels from the PMC passes committed under profiles/ (same workload)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_spconv.json")))
-        if pmc["workload"] == workload:
-            traffic = int(pmc["fetch_corrected_bytes_per_step"] + pmc["write_bytes_per_step"])
-            traffic_note = ("bytes per step over the same kernels: FETCH_SIZE x2 (gfx950 correction, upper bound for 16-B gathers) + WRITE_SIZE, "
-                            "rocprofv3 --pmc in separate passes, profiles/r01_pmc_hbm_spconv.json")
-    except (OSError, KeyError, ValueError):
-        pass
+    for name in ("r02_pmc_hbm_spconv.json", "r01_pmc_hbm_spconv.json"):
+        try:  # HBM bytes of these kernels from the PMC passes committed under profiles/ (same workload)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if pmc["workload"] == workload:
+                traffic = int(pmc["fetch_corrected_bytes_per_step"] + pmc["write_bytes_per_step"])
+                traffic_note = ("bytes per step over the same kernels: FETCH_SIZE x2 (gfx950 correction, upper bound for 16-B gathers) + WRITE_SIZE, "
+                                "rocprofv3 --pmc in separate passes, profiles/" + name)
+                break
+        except (OSError, KeyError, ValueError):
+            pass
+    other = {}
+    if bn["ms"] > 0:
+        gbs = bn["bytes"] / (bn["ms"] * 1e-3) / 1e9
+        other["batchnorm (bn_partial / bn_finalize / bn_apply, fwd + bwd)"] = {
+            "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "launches": bn["launches"], "ms": round(bn["ms"], 3), "algorithmic_bytes_per_step": int(bn["bytes"]),
+            "bytes_rule": "4*N*C per row matrix read or written: forward x (+residual) in, y out -- x twice when the statistics are not produced by the "
+                          "convolution's reduce pass; backward two passes over (gy, x, y-mask), gx (+ residual gradient) out"}
+    if attn["ms"] > 0:
+        tf = attn["flops"] / (attn["ms"] * 1e-3) / 1e12
+        other["attention (attn_fwd / attn_bwd_kv / attn_bwd_q)"] = {
+            "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+            "launches": attn["launches"], "ms": round(attn["ms"], 3),
+            "flops_rule": "2*B*H*T^2*64 per product; 2 products forward (S, O), 7 backward (S, dP, dV, dK; S^T, dP^T, dQ)"}
     return {
-        "bound": "hbm", "kernel": "pairs_gemm_kernel + spconv_reduce_kernel + pairs_wgrad_kernel (sparse conv fwd / dgrad / wgrad)",
+        "bound": "hbm", "kernel": "pairs_gemm_kernel + spconv_reduce(_stats)_kernel + pairs_wgrad_kernel + wgrad_reduce_kernel (sparse conv fwd / dgrad / wgrad)",
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
         "traffic": traffic, "traffic_note": traffic_note,
-        "launches": len(log), "convolutions": n_conv, "avg_conv_us": round(1e3 * tot_ms / max(n_conv, 1), 2),
+        "launches": n_sp, "convolutions": n_conv, "avg_conv_us": round(1e3 * tot_ms / max(n_conv, 1), 2),
         "algorithmic_bytes_per_step": int(tot_bytes), "useful_tflops": round(tot_flops / (tot_ms * 1e-3) / 1e12, 3),
         "mfma_f32_peak_tflops": MFMA_F32_PEAK_TFLOPS,
+        "measured_on": "the last timed step, which issues both branches on one stream with a HIP event pair around every logged launch "
+                       "(so a kernel's duration is its own); that step is part of `value`",
         "per_kernel": {k: {"launches": v[0], "ms": round(v[1], 3), "avg_us": round(1e3 * v[1] / v[0], 1),
                            "GB/s": round(v[2] / (v[1] * 1e-3) / 1e9, 1), "useful_TFLOP/s": round(v[3] / (v[1] * 1e-3) / 1e12, 2)}
                        for k, v in per_kind.items()},
+        "other_kernel_groups": other,
     }
 
 

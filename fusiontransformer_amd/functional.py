@@ -539,8 +539,9 @@ class _BatchNormTrain(torch.autograd.Function):
         invstd = _empty((c,), F32, x)
         ws_bytes = int(L.ftx_bn_workspace_bytes(n, c))
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
-        check(L.ftx_bn_train_fwd(ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps),
-                                 n, c, int(relu), ptr(y), ptr(mean), ptr(invstd), ptr(ws), ws_bytes, stream()), "ftx_bn_train_fwd")
+        _log_launch("bn_fwd", dict(n=n, c=c, reads=2 + (residual is not None), writes=1), lambda: check(L.ftx_bn_train_fwd(
+            ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps),
+            n, c, int(relu), ptr(y), ptr(mean), ptr(invstd), ptr(ws), ws_bytes, stream()), "ftx_bn_train_fwd"))
         ctx.save_for_backward(x, y, gamma, mean, invstd)
         ctx.relu = int(relu)
         ctx.has_res = residual is not None
@@ -588,8 +589,10 @@ def _bn_backward_launch(gy, x, y, gamma, mean, invstd, relu, has_res):
     gbeta = _empty((c,), F32, x)
     ws_bytes = int(L.ftx_bn_workspace_bytes(n, c))
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
-    check(L.ftx_bn_train_bwd(ptr(gy), ptr(x), ptr(y), ptr(gamma), ptr(mean), ptr(invstd), n, c, int(relu), ptr(gx), ptr(gres), ptr(ggamma),
-                             ptr(gbeta), ptr(ws), ws_bytes, stream()), "ftx_bn_train_bwd")
+    # two passes (statistics, apply), each reading gy and x (and y for the ReLU mask); one or two row matrices written
+    _log_launch("bn_bwd", dict(n=n, c=c, reads=2 * (2 + (1 if relu else 0)), writes=1 + (1 if has_res else 0)), lambda: check(L.ftx_bn_train_bwd(
+        ptr(gy), ptr(x), ptr(y), ptr(gamma), ptr(mean), ptr(invstd), n, c, int(relu), ptr(gx), ptr(gres), ptr(ggamma),
+        ptr(gbeta), ptr(ws), ws_bytes, stream()), "ftx_bn_train_bwd"))
     return gx, gres, ggamma, gbeta
 
 
@@ -620,8 +623,9 @@ class _ConvBNTrain(torch.autograd.Function):
             y = torch.empty_like(x)
             ws_bytes = int(L.ftx_bn_workspace_bytes(n_out, co))
             ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
-            check(L.ftx_bn_train_fwd(ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps),
-                                     n_out, co, int(relu), ptr(y), ptr(mean), ptr(invstd), ptr(ws), ws_bytes, stream()), "ftx_bn_train_fwd")
+            _log_launch("bn_fwd", dict(n=n_out, c=co, reads=2 + (residual is not None), writes=1), lambda: check(L.ftx_bn_train_fwd(
+                ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps),
+                n_out, co, int(relu), ptr(y), ptr(mean), ptr(invstd), ptr(ws), ws_bytes, stream()), "ftx_bn_train_fwd"))
         else:
             gather, pos = (km.pair_out, km.pos_t) if transposed else (km.pair_in, km.pos)
             tmp = _empty((km.n_pairs, co), F32, feats)
@@ -634,9 +638,9 @@ class _ConvBNTrain(torch.autograd.Function):
                 ptr(feats), n_in, ptr(gather), ptr(kernel), 0, ptr(km.koff), km.n_pairs, ca, co, kvol, ptr(tmp), stream()), "ftx_spconv_pairs_gemm"))
             _log_launch("spconv_reduce", meta, lambda: check(L.ftx_spconv_reduce_stats(
                 ptr(tmp), ptr(pos), n_out, co, kvol, ptr(x), ptr(part), nb, stream()), "ftx_spconv_reduce_stats"))
-            check(L.ftx_bn_train_fwd_partials(ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum),
-                                              float(eps), n_out, co, int(relu), ptr(y), ptr(mean), ptr(invstd), ptr(part), nb, stream()),
-                  "ftx_bn_train_fwd_partials")
+            _log_launch("bn_fwd", dict(n=n_out, c=co, reads=1 + (residual is not None), writes=1), lambda: check(L.ftx_bn_train_fwd_partials(
+                ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum),
+                float(eps), n_out, co, int(relu), ptr(y), ptr(mean), ptr(invstd), ptr(part), nb, stream()), "ftx_bn_train_fwd_partials"))
         ctx.save_for_backward(feats, kernel, x, y, gamma, mean, invstd)
         ctx.km, ctx.transposed, ctx.relu, ctx.has_res = km, transposed, int(relu), residual is not None
         return y
@@ -752,7 +756,8 @@ class _Attention(torch.autograd.Function):
             raise ValueError(f"attention: qkv must be (B, T, 3, heads, 64), got {tuple(qkv.shape)}")
         out = _empty((b, t, h * d), F32, qkv)
         lse = _empty((b, h, t), F32, qkv)
-        check(L.ftx_attn_fwd(ptr(qkv), b, t, h, d, float(scale), ptr(out), ptr(lse), stream()), "ftx_attn_fwd")
+        _log_launch("attn_fwd", dict(b=b, t=t, h=h, d=d, products=2), lambda: check(L.ftx_attn_fwd(
+            ptr(qkv), b, t, h, d, float(scale), ptr(out), ptr(lse), stream()), "ftx_attn_fwd"))
         ctx.save_for_backward(qkv, out, lse)
         ctx.scale = float(scale)
         return out
@@ -766,7 +771,8 @@ class _Attention(torch.autograd.Function):
         gqkv = torch.empty_like(qkv)
         ws_bytes = int(L.ftx_attn_bwd_workspace_bytes(b, t, h))
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=qkv.device)
-        check(L.ftx_attn_bwd(ptr(qkv), ptr(out), ptr(go), ptr(lse), b, t, h, d, ctx.scale, ptr(gqkv), ptr(ws), ws_bytes, stream()), "ftx_attn_bwd")
+        _log_launch("attn_bwd", dict(b=b, t=t, h=h, d=d, products=7), lambda: check(L.ftx_attn_bwd(
+            ptr(qkv), ptr(out), ptr(go), ptr(lse), b, t, h, d, ctx.scale, ptr(gqkv), ptr(ws), ws_bytes, stream()), "ftx_attn_bwd"))
         return gqkv, None
 
 
