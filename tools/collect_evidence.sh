@@ -1,16 +1,25 @@
 #!/bin/bash
-# Round evidence on the GPU box: tests, bench line, rocprofv3 kernel stats (two-stream and serial issue), HBM PMC passes.
-# usage (from the repo root, via gpurun): bash tools/collect_evidence.sh <out dir under gpurun_out>
+# Round evidence on the GPU box: tests, bench line, rocprofv3 kernel stats (two-stream and serial issue), HBM PMC passes, SQ counters and
+# the per-layer micro-benchmark of the sparse-conv kernels, and the 2-rank data-parallel rehearsal of bench.py on the one GPU.
+# usage (from the repo root, via gpurun): bash tools/collect_evidence.sh <out dir under gpurun_out> [steps: all | quick]
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; mkdir -p $O
 cd $R && timeout -k 10 900 python -m pytest tests -q -m gpu 2>&1 | tail -3 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt
 python bench.py > $O/bench.json 2> $O/bench.err && tail -c 600 $O/bench.json
+python tools/bench_spconv.py > $O/spconv_layer_micro.txt 2>&1; tail -1 $O/spconv_layer_micro.txt
+# N > 1 code path (bucketed overlapped all-reduce, per-rank batches) rehearsed as 2 ranks on this one GPU over gloo: NOT a scaling number
+FTX_DIST_BACKEND=gloo FTX_FORCE_DEVICE=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
+  bench.py --gpus 2 --steps 6 --warmup 3 --no-cpu-baseline > $O/bench_2ranks_one_gpu_gloo.json 2> $O/bench_2ranks.err; tail -c 300 $O/bench_2ranks_one_gpu_gloo.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ev_two -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_two_bench.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ev_two -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-batch1 --no-nuscenes > $O/prof_two_bench.json 2>/dev/null
 cp $(find /tmp/ev_two -name "*kernel_stats.csv" | head -1) $O/rocprof_two_stream_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ev_ser -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --serial-branches --no-tune-gemm > $O/prof_serial_bench.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ev_ser -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-batch1 --no-nuscenes --serial-branches > $O/prof_serial_bench.json 2>/dev/null
 cp $(find /tmp/ev_ser -name "*kernel_stats.csv" | head -1) $O/rocprof_serial_stats.csv
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/ev_f -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-tune-gemm > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/ev_w -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-tune-gemm > /dev/null 2>&1
+python3 $R/tools/prof_summary.py $O/rocprof_serial_stats.csv 7 > $O/rocprof_serial_summary.txt; head -22 $O/rocprof_serial_summary.txt
+python3 $R/tools/prof_summary.py $O/rocprof_two_stream_stats.csv 7 > $O/rocprof_two_stream_summary.txt
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/ev_f -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch1 --no-nuscenes > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/ev_w -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch1 --no-nuscenes > /dev/null 2>&1
 python3 $R/tools/pmc_hbm.py $(find /tmp/ev_f -name "*counter_collection.csv" | head -1) $(find /tmp/ev_w -name "*counter_collection.csv" | head -1) 3 > $O/pmc_hbm_spconv.json
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d /tmp/ev_sq -- python3 $R/tools/bench_spconv.py --iters 1 > /dev/null 2>&1
+python3 $R/tools/pmc_sq.py /tmp/ev_sq pairs_ reduce > $O/pmc_spconv_sq.txt
 ls -la $O

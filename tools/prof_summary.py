@@ -5,7 +5,7 @@ import collections, csv, sys
 def cat(name):
     if 'naive_conv' in name or 'miopenSp3' in name or 'igemm' in name or 'Im2d2Col' in name or 'Col2Im' in name: return 'MIOpen conv'
     if 'pairs_gemm_kernel' in name: return 'ftx spconv pairs_gemm'
-    if 'spconv_reduce_kernel' in name: return 'ftx spconv reduce'
+    if 'spconv_reduce' in name: return 'ftx spconv reduce'
     if 'pairs_wgrad_kernel' in name or 'wgrad_reduce' in name: return 'ftx spconv wgrad'
     if 'attn_' in name: return 'ftx attention'
     if name.startswith('Cijk'): return 'hipBLASLt GEMM (Cijk)'
@@ -13,7 +13,7 @@ def cat(name):
     if 'voxelize' in name: return 'ftx vox/devox'
     if 'lift' in name or 'resample' in name: return 'ftx lift/resample'
     if any(k in name for k in ['hash', 'table_', 'kernel_map', 'count_kernel', 'iota', 'gather_coords', 'downsample', 'trilinear', 'floor_coords',
-                               'fill_m1', 'koff_kernel', 'pairs_scatter', 'rocprim']): return 'ftx index'
+                               'fill_m1', 'koff_kernel', 'pairs_scatter', 'rocprim', 'sorted_rank']): return 'ftx index'
     if 'softmax' in name.lower(): return 'torch softmax'
     if 'elementwise' in name or 'FillFunctor' in name: return 'torch elementwise'
     if 'reduce_kernel' in name: return 'torch reduce'
