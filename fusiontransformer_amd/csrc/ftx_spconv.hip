@@ -361,6 +361,17 @@ static void launch_pairs_gemm(int nt, dim3 grid, hipStream_t st, const float *A,
 }
 
 #include "ftx_spconv_dma.h"
+#include "ftx_spconv_split.h"
+
+// Arithmetic of the matrix products of the sparse convolution: 0 = exact-f32 MFMA (default), 1 = three-way bf16 operand split on the
+// bf16 matrix cores, f32-equivalent accuracy (ftx_spconv_split.h).  Process-wide switch; FTX_SPCONV_SPLIT=1 sets the initial value.
+static int g_split = -1;
+static bool split_on() {
+  if (g_split < 0) g_split = getenv("FTX_SPCONV_SPLIT") ? (atoi(getenv("FTX_SPCONV_SPLIT")) != 0) : 0;
+  return g_split != 0;
+}
+extern "C" void ftx_spconv_set_split(int32_t on) { g_split = on ? 1 : 0; }
+extern "C" int32_t ftx_spconv_get_split(void) { return split_on() ? 1 : 0; }
 
 static int gemm_nt(int co) {
   int nt = co >= 128 ? 4 : (co + 31) / 32;
@@ -395,7 +406,10 @@ extern "C" int ftx_spconv_pairs_gemm(const float *A, int64_t rows_a, const int32
   const int nt = gemm_nt(co), rt = gemm_rt(n_pairs, kvol, ca, co);
   const unsigned tiles_ub = (unsigned)(ceil_div(n_pairs, TILE_P * rt) + kvol);  // sum_k ceil(cnt_k/tile) <= P/tile + kvol
   dim3 grid(tiles_ub, (unsigned)ceil_div(co, 32 * nt));
-  if (rt == 1 && gemm_use_dma(n_pairs, ca, co, nt)) {
+  if (split_on()) {
+    dim3 g1((unsigned)(ceil_div(n_pairs, TILE_P) + kvol), grid.y);
+    split::launch(nt, g1, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0, nullptr, 0);
+  } else if (rt == 1 && gemm_use_dma(n_pairs, ca, co, nt)) {
     FTX_REQUIRE(dma::dispatch(nt, grid, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0) == 0,
                 "ftx_spconv_pairs_gemm: could not configure the LDS-DMA kernel");
   } else if (rt == 2)
@@ -419,7 +433,10 @@ extern "C" int ftx_spconv_pairs_gemm_scatter(const float *A, int64_t rows_a, con
   hipStream_t st = (hipStream_t)stream;
   const int nt = gemm_nt(co);
   dim3 grid((unsigned)(ceil_div(n_pairs, TILE_P) + kvol), (unsigned)ceil_div(co, 32 * nt));
-  launch_pairs_gemm<1>(nt, grid, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, out, nullptr, 0, scatter, rows_out);
+  if (split_on())
+    split::launch(nt, grid, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, out, nullptr, 0, scatter, rows_out);
+  else
+    launch_pairs_gemm<1>(nt, grid, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, out, nullptr, 0, scatter, rows_out);
   return check_launch("ftx_spconv_pairs_gemm_scatter");
 }
 
@@ -435,7 +452,10 @@ extern "C" int ftx_rows_gemm(const float *A, int64_t n, const float *W, int32_t 
   hipStream_t st = (hipStream_t)stream;
   const int nt = gemm_nt(co), rt = gemm_rt(n, 1, ca, co);
   dim3 grid((unsigned)ceil_div(n, TILE_P * rt), (unsigned)ceil_div(co, 32 * nt));
-  if (rt == 1 && gemm_use_dma(n, ca, co, nt)) {
+  if (split_on()) {
+    dim3 g1((unsigned)ceil_div(n, TILE_P), grid.y);
+    split::launch(nt, g1, st, A, n, nullptr, W, w_transposed, nullptr, ca, co, 1, out, bias, n, nullptr, 0);
+  } else if (rt == 1 && gemm_use_dma(n, ca, co, nt)) {
     FTX_REQUIRE(dma::dispatch(nt, grid, st, A, n, nullptr, W, w_transposed, nullptr, ca, co, 1, out, bias, n) == 0,
                 "ftx_rows_gemm: could not configure the LDS-DMA kernel");
   } else if (rt == 2)

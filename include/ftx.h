@@ -176,6 +176,14 @@ int ftx_spconv_pairs_gemm(const float *A, int64_t rows_a, const int32_t *gather,
  * named by scatter are left untouched.  Replaces pairs_gemm + reduce (no tmp round trip). */
 int ftx_spconv_pairs_gemm_scatter(const float *A, int64_t rows_a, const int32_t *gather, const int32_t *scatter, const float *W, int32_t w_transposed, const int32_t *koff, int64_t n_pairs, int32_t ca, int32_t co, int32_t kvol, float *out, int64_t rows_out, void *stream);
 
+/* Arithmetic of the sparse-convolution matrix products (process-wide switch, initial value from FTX_SPCONV_SPLIT):
+ *   0 (default)  exact-f32 MFMA (v_mfma_f32_32x32x2_f32): bit-for-bit an f32 fma chain;
+ *   1            every f32 operand split in-kernel into three bf16 terms (exact), six bf16-MFMA partial products accumulated in
+ *                f32: per-product error < 2^-24, i.e. f32-equivalent, at 2.67x less matrix-pipe time.  Deterministic, but not
+ *                bit-identical to mode 0.  Affects ftx_spconv_pairs_gemm(_scatter), ftx_rows_gemm and ftx_spconv_pairs_wgrad. */
+void ftx_spconv_set_split(int32_t on);
+int32_t ftx_spconv_get_split(void);
+
 /* Dense rows on the same tile code: out[r,:] = A[r,:] @ W (+ bias), r < n.  W as above with kvol = 1;
  * bias (co) may be NULL.  Replaces the point-branch nn.Linear layers (models/spvcnn.py:164-180,
  * models/middle_fusion.py:18-29) and the kernel_size=1 spnn.Conv3d (spvcnn.py:71-75). */

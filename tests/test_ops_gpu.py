@@ -264,6 +264,52 @@ def test_fused_conv_batchnorm_node_matches_oracle_ops(env, ca, co, ks, cur, s, t
     assert torch.equal(yg2, yg.detach())
 
 
+@pytest.mark.parametrize("ca,co,ks,cur,s", [(32, 32, 3, 1, 1), (128, 96, 3, 1, 1), (64, 64, 2, 1, 2), (384, 256, 3, 2, 1), (4, 32, 3, 1, 1), (96, 20, 3, 1, 1)])
+def test_split_bf16_arithmetic_is_f32_accurate(env, ca, co, ks, cur, s):
+    """The opt-in bf16x3 arithmetic of the sparse-conv matrix products (ftx_spconv_set_split(1): every f32 operand split exactly into
+    three bf16 terms, six bf16-MFMA partial products, f32 accumulate) is held to the SAME accuracy as the exact-f32 MFMA kernels:
+    forward, data gradient and weight gradient are compared with a float64 evaluation, and the split path's error may not exceed
+    1.5x the exact path's (+ one f32 ulp of the largest value).  Operands span 12 binary orders of magnitude."""
+    spf, O = env
+    from fusiontransformer_amd import _lib
+    from fusiontransformer_amd.sparse import CoordinateManager
+    L = _lib.load()
+    rng = np.random.default_rng(21)
+    c = random_coords(rng, 3000, extent=40, batch=2)
+    c = c[np.argsort(O.sphash(c))]
+    cm = CoordinateManager()
+    cm.coords[1] = dev(c)
+    st = 1
+    while st < cur:
+        cm.kernel_map(2, st, 2)
+        st *= 2
+    km = cm.kernel_map(ks, cur, s)
+    idx_query, _ = O.build_kernel_map(cm.coords[cur].cpu().numpy(), cur, ks, s)
+    x = (rng.standard_normal((km.n_in, ca)) * np.exp2(rng.integers(-6, 7, size=(km.n_in, 1)))).astype(np.float32)
+    w = (rng.standard_normal((ks ** 3, ca, co)) / np.sqrt(ca * ks ** 3)).astype(np.float32)
+    go = rng.standard_normal((km.n_out, co)).astype(np.float32)
+    xo, wo = torch.from_numpy(x).double().requires_grad_(True), torch.from_numpy(w).double().requires_grad_(True)
+    yo = O.sparseconv_op(xo, wo, idx_query, km.n_out, False)
+    yo.backward(torch.from_numpy(go).double())
+    res = {}
+    try:
+        for mode in (0, 1):
+            L.ftx_spconv_set_split(mode)
+            assert L.ftx_spconv_get_split() == mode
+            xg, wg = dev(x).requires_grad_(True), dev(w).requires_grad_(True)
+            yg = spf.sparse_conv(xg, wg, km, False)
+            yg.backward(dev(go))
+            res[mode] = [t.detach().cpu().double() for t in (yg, xg.grad, wg.grad)]
+    finally:
+        L.ftx_spconv_set_split(0)
+    for name, ref, exact, split in zip(("forward", "dgrad", "wgrad"), (yo.detach(), xo.grad, wo.grad), res[0], res[1]):
+        e_exact, e_split = (exact - ref).abs().max().item(), (split - ref).abs().max().item()
+        ulp = ref.abs().max().item() * 2.0 ** -23
+        assert e_split <= 1.5 * e_exact + ulp, (name, e_exact, e_split)
+        assert (split - ref).norm().item() <= 1.5 * (exact - ref).norm().item() + 1e-12, name
+    assert not torch.equal(res[0][0], res[1][0]) or ca <= 4   # the switch really selects another kernel
+
+
 @pytest.mark.parametrize("n,ca,co", [(5000, 32, 256), (3001, 256, 128), (777, 96, 20), (4096, 128, 96), (130, 4, 32), (1, 384, 256)])
 def test_rows_linear_and_matmul_match_torch(env, n, ca, co):
     spf, O = env
