@@ -22,6 +22,36 @@ def _empty(shape, dtype, like):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
 
+# Kernel workspaces (BatchNorm / weight-gradient partials, sort and scan temporaries) live in ONE growing buffer per (device, stream):
+# a workspace is only touched by the kernels of the call that receives it, and calls on one stream execute in order, so the next
+# call may reuse the bytes.  This takes two allocator round trips and a size query through ctypes out of every such call (~150 per
+# training step).  While a stream is being captured into a HIP graph the buffer must not be baked in (it can be re-grown later), so
+# capture falls back to a fresh allocation from the graph's pool.
+_SCRATCH = {}
+_WS_BYTES = {}
+
+
+def _ws_bytes(fn_name, *args):
+    key = (fn_name,) + args
+    v = _WS_BYTES.get(key)
+    if v is None:
+        v = _WS_BYTES[key] = int(getattr(_lib.load(), fn_name)(*args))
+        if len(_WS_BYTES) > 4096:
+            _WS_BYTES.clear()
+    return v
+
+
+def _scratch(nbytes, like):
+    dev = like.device
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    key = (dev.index, stream())
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.shape[0] < nbytes:
+        buf = _SCRATCH[key] = torch.empty((max(int(nbytes * 1.25), 1 << 22),), dtype=torch.uint8, device=dev)
+    return buf
+
+
 # ---------------------------------------------------------------- integer side
 def sphash(coords: torch.Tensor, offsets: torch.Tensor | None = None) -> torch.Tensor:
     """spf.sphash: (N,4) int32 -> (N,) int64, or with (K,3) offsets -> (K,N)."""
@@ -96,8 +126,8 @@ def unique_sorted(keys: torch.Tensor):
     uniq = _empty((n,), I64, keys)
     first = _empty((n,), I32, keys)
     cnt = torch.zeros((1,), dtype=I32, device=keys.device)
-    ws_bytes = int(L.ftx_unique_workspace_bytes(n))
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=keys.device)
+    ws_bytes = _ws_bytes("ftx_unique_workspace_bytes", n)
+    ws = _scratch(ws_bytes, keys)
     check(L.ftx_unique_sorted(ptr(keys), n, ptr(uniq), ptr(first), ptr(cnt), ptr(ws), ws_bytes, stream()), "ftx_unique_sorted")
     return uniq, first, cnt
 
@@ -162,8 +192,8 @@ def kernel_map_count(nbr: torch.Tensor):
     k, n_out = nbr.shape
     pos = torch.empty_like(nbr)
     koff = _empty((k + 1,), I32, nbr)
-    ws_bytes = int(L.ftx_kernel_map_count_workspace_bytes(n_out, k))
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=nbr.device)
+    ws_bytes = _ws_bytes("ftx_kernel_map_count_workspace_bytes", n_out, k)
+    ws = _scratch(ws_bytes, nbr)
     check(L.ftx_kernel_map_count(ptr(nbr), n_out, k, ptr(pos), ptr(koff), ptr(ws), ws_bytes, stream()), "ftx_kernel_map_count")
     return pos, koff
 
@@ -205,8 +235,8 @@ class Segments:
         self.m = int(m)
         self.order = _empty((n,), I32, keys)
         self.seg_off = _empty((self.m + 1,), I32, keys)
-        ws_bytes = int(L.ftx_segment_workspace_bytes(n, self.m))
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=keys.device)
+        ws_bytes = _ws_bytes("ftx_segment_workspace_bytes", n, self.m)
+        ws = _scratch(ws_bytes, keys)
         check(L.ftx_segment_build(ptr(keys), n, self.m, ptr(self.order), ptr(self.seg_off), ptr(ws), ws_bytes, stream()), "ftx_segment_build")
 
 
@@ -363,8 +393,8 @@ def _spconv_wgrad(A, idx_a, G, idx_g, koff, n_pairs):
     rows_g, cg = G.shape
     kvol = koff.shape[0] - 1
     dW = _empty((kvol, ca, cg), F32, A)
-    ws_bytes = int(L.ftx_spconv_pairs_wgrad_workspace_bytes(n_pairs, ca, cg, kvol))
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=A.device)
+    ws_bytes = _ws_bytes("ftx_spconv_pairs_wgrad_workspace_bytes", n_pairs, ca, cg, kvol)
+    ws = _scratch(ws_bytes, A)
 
     def launch():
         check(L.ftx_spconv_pairs_wgrad(ptr(A), rows_a, ptr(idx_a), ptr(G), rows_g, ptr(idx_g), ptr(koff), n_pairs, ca, cg, kvol, ptr(dW), ptr(ws),
@@ -448,8 +478,8 @@ def _rows_wgrad(A, G):
     n, ca = A.shape
     cg = G.shape[1]
     dW = _empty((1, ca, cg), F32, A)
-    ws_bytes = int(L.ftx_spconv_pairs_wgrad_workspace_bytes(n, ca, cg, 1))
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=A.device)
+    ws_bytes = _ws_bytes("ftx_spconv_pairs_wgrad_workspace_bytes", n, ca, cg, 1)
+    ws = _scratch(ws_bytes, A)
     check(L.ftx_spconv_pairs_wgrad(ptr(A), n, 0, ptr(G), n, 0, 0, n, ca, cg, 1, ptr(dW), ptr(ws), ws_bytes, stream()), "ftx_spconv_pairs_wgrad(dense)")
     return dW[0]
 
@@ -537,8 +567,8 @@ class _BatchNormTrain(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = _empty((c,), F32, x)
         invstd = _empty((c,), F32, x)
-        ws_bytes = int(L.ftx_bn_workspace_bytes(n, c))
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+        ws_bytes = _ws_bytes("ftx_bn_workspace_bytes", n, c)
+        ws = _scratch(ws_bytes, x)
         _log_launch("bn_fwd", dict(n=n, c=c, reads=2 + (residual is not None), writes=1), lambda: check(L.ftx_bn_train_fwd(
             ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps),
             n, c, int(relu), ptr(y), ptr(mean), ptr(invstd), ptr(ws), ws_bytes, stream()), "ftx_bn_train_fwd"))
@@ -587,8 +617,8 @@ def _bn_backward_launch(gy, x, y, gamma, mean, invstd, relu, has_res):
     gres = torch.empty_like(x) if has_res else None
     ggamma = _empty((c,), F32, x)
     gbeta = _empty((c,), F32, x)
-    ws_bytes = int(L.ftx_bn_workspace_bytes(n, c))
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+    ws_bytes = _ws_bytes("ftx_bn_workspace_bytes", n, c)
+    ws = _scratch(ws_bytes, x)
     # two passes (statistics, apply), each reading gy and x (and y for the ReLU mask); one or two row matrices written
     _log_launch("bn_bwd", dict(n=n, c=c, reads=2 * (2 + (1 if relu else 0)), writes=1 + (1 if has_res else 0)), lambda: check(L.ftx_bn_train_bwd(
         ptr(gy), ptr(x), ptr(y), ptr(gamma), ptr(mean), ptr(invstd), n, c, int(relu), ptr(gx), ptr(gres), ptr(ggamma),
@@ -621,8 +651,8 @@ class _ConvBNTrain(torch.autograd.Function):
         if direct:
             x = _conv_forward(feats, kernel, km, transposed)
             y = torch.empty_like(x)
-            ws_bytes = int(L.ftx_bn_workspace_bytes(n_out, co))
-            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+            ws_bytes = _ws_bytes("ftx_bn_workspace_bytes", n_out, co)
+            ws = _scratch(ws_bytes, x)
             _log_launch("bn_fwd", dict(n=n_out, c=co, reads=2 + (residual is not None), writes=1), lambda: check(L.ftx_bn_train_fwd(
                 ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps),
                 n_out, co, int(relu), ptr(y), ptr(mean), ptr(invstd), ptr(ws), ws_bytes, stream()), "ftx_bn_train_fwd"))
