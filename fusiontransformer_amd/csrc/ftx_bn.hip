@@ -3,16 +3,19 @@
 // (models/spvcnn.py:30-31,71-79,100-102,164-180).  HBM-bound: x is read twice in the
 // forward (statistics, apply) and the output written once; statistics accumulate in
 // float64 so mean/var do not depend on how rows are split over workgroups.
+#include <cstdlib>
 #include "ftx_common.h"
 
 using namespace ftx;
 
-constexpr int BN_MAX_BLOCKS = 1024;
-constexpr int BN_ROWS_PER_BLOCK = 128;
-
+// Grid of the statistics passes.  They stream 1-3 row matrices once and are bound by loads in flight, not by bytes: at 128 rows per
+// block the 81k-row level ran 635 blocks (2.5 per CU) and reached 1.7 TB/s; FTX_BN_ROWS / FTX_BN_MAX_BLOCKS keep the knobs measurable.
 static int bn_blocks(int64_t n) {
-  int64_t b = ceil_div(n, BN_ROWS_PER_BLOCK);
-  if (b > BN_MAX_BLOCKS) b = BN_MAX_BLOCKS;
+  static const int rows = getenv("FTX_BN_ROWS") ? atoi(getenv("FTX_BN_ROWS")) : 48;
+  static const int maxb = getenv("FTX_BN_MAX_BLOCKS") ? atoi(getenv("FTX_BN_MAX_BLOCKS")) : 2048;
+  int64_t b = ceil_div(n, rows > 0 ? rows : 48);
+  if (b > maxb) b = maxb;
+  if (b > 4096) b = 4096;
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -59,16 +62,26 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict
       mu = *(const float4 *)&mean[cg * 4];
       is = *(const float4 *)&invstd[cg * 4];
     }
-    for (int64_t r = r0 + rl; r < r1; r += RL) {
-      float4 xv = *(const float4 *)&x[r * c + cg * 4];
-      float4 gv = make_float4(0, 0, 0, 0), yv = gv;
-      if (gy) gv = *(const float4 *)&gy[r * c + cg * 4];
-      if (y) yv = *(const float4 *)&y[r * c + cg * 4];
+    auto accumulate = [&](const float4 &xv, const float4 &gv, const float4 &yv) {
       double a, b;
       Op::eval(xv.x, gv.x, yv.x, mu.x, is.x, relu, a, b); s0[0] += a; s1[0] += b;
       Op::eval(xv.y, gv.y, yv.y, mu.y, is.y, relu, a, b); s0[1] += a; s1[1] += b;
       Op::eval(xv.z, gv.z, yv.z, mu.z, is.z, relu, a, b); s0[2] += a; s1[2] += b;
       Op::eval(xv.w, gv.w, yv.w, mu.w, is.w, relu, a, b); s0[3] += a; s1[3] += b;
+    };
+    const float4 zero4 = make_float4(0, 0, 0, 0);
+    int64_t r = r0 + rl;
+    for (; r + RL < r1; r += 2 * RL) {   // two rows per trip: six independent 16-byte loads in flight per thread, summed in row order
+      const int64_t o0 = r * c + cg * 4, o1 = (r + RL) * c + cg * 4;
+      const float4 xa = *(const float4 *)&x[o0], xb = *(const float4 *)&x[o1];
+      const float4 ga = gy ? *(const float4 *)&gy[o0] : zero4, gb = gy ? *(const float4 *)&gy[o1] : zero4;
+      const float4 ya = y ? *(const float4 *)&y[o0] : zero4, yb = y ? *(const float4 *)&y[o1] : zero4;
+      accumulate(xa, ga, ya);
+      accumulate(xb, gb, yb);
+    }
+    for (; r < r1; r += RL) {
+      const int64_t o0 = r * c + cg * 4;
+      accumulate(*(const float4 *)&x[o0], gy ? *(const float4 *)&gy[o0] : zero4, y ? *(const float4 *)&y[o0] : zero4);
     }
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -120,31 +133,51 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const double *__re
   }
 }
 
-__global__ void bn_apply_fwd_kernel(const float *__restrict__ x, const float *__restrict__ res, const float *__restrict__ gamma,
-                                    const float *__restrict__ beta, const float *__restrict__ mean, const float *__restrict__ invstd,
-                                    int64_t n, int c, int relu, float *__restrict__ y) {
+// Apply passes: thread (column group cg, row lane rl) keeps its four channels' constants in registers and walks rows rl, rl + RL*grid, ...
+// two at a time (independent 16-byte loads in flight); RL = 256 / (c/4) rows per block and trip.
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float *__restrict__ x, const float *__restrict__ res, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, const float *__restrict__ mean,
+                                                           const float *__restrict__ invstd, int64_t n, int c, int relu, float *__restrict__ y) {
   const int c4 = c >> 2;
-  const int64_t total = n * c4;
-  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    int col = (int)(e % c4) * 4;
-    float4 xv = *(const float4 *)&x[e * 4];
-    float4 mu = *(const float4 *)&mean[col], is = *(const float4 *)&invstd[col];
-    float4 g = *(const float4 *)&gamma[col], b = *(const float4 *)&beta[col];
-    float4 o;
-    o.x = (xv.x - mu.x) * is.x * g.x + b.x;
-    o.y = (xv.y - mu.y) * is.y * g.y + b.y;
-    o.z = (xv.z - mu.z) * is.z * g.z + b.z;
-    o.w = (xv.w - mu.w) * is.w * g.w + b.w;
+  const int RL = 256 / c4 > 0 ? 256 / c4 : 1;
+  const int cg = threadIdx.x % c4, rl = threadIdx.x / c4;
+  if (rl >= RL) return;
+  const int col = cg * 4;
+  const float4 mu = *(const float4 *)&mean[col], is = *(const float4 *)&invstd[col];
+  const float4 g = *(const float4 *)&gamma[col], b = *(const float4 *)&beta[col];
+  auto one = [&](int64_t r) {
+    const int64_t o = r * c + col;
+    const float4 xv = *(const float4 *)&x[o];
+    float4 ov;
+    ov.x = (xv.x - mu.x) * is.x * g.x + b.x;
+    ov.y = (xv.y - mu.y) * is.y * g.y + b.y;
+    ov.z = (xv.z - mu.z) * is.z * g.z + b.z;
+    ov.w = (xv.w - mu.w) * is.w * g.w + b.w;
     if (res) {
-      float4 rv = *(const float4 *)&res[e * 4];
-      o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+      const float4 rv = *(const float4 *)&res[o];
+      ov.x += rv.x; ov.y += rv.y; ov.z += rv.z; ov.w += rv.w;
     }
     if (relu) {
-      o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
-      o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+      ov.x = ov.x > 0.f ? ov.x : 0.f; ov.y = ov.y > 0.f ? ov.y : 0.f;
+      ov.z = ov.z > 0.f ? ov.z : 0.f; ov.w = ov.w > 0.f ? ov.w : 0.f;
     }
-    *(float4 *)&y[e * 4] = o;
+    *(float4 *)&y[o] = ov;
+  };
+  const int64_t stride = (int64_t)gridDim.x * RL;
+  int64_t r = (int64_t)blockIdx.x * RL + rl;
+  for (; r + stride < n; r += 2 * stride) {
+    one(r);
+    one(r + stride);
   }
+  if (r < n) one(r);
+}
+
+static unsigned bn_apply_grid(int64_t n, int c) {
+  const int c4 = c / 4;
+  const int rl = 256 / c4 > 0 ? 256 / c4 : 1;
+  int64_t g = ceil_div(n, 2 * (int64_t)rl);   // two rows per thread
+  if (g > 4096) g = 4096;
+  return (unsigned)(g < 1 ? 1 : g);
 }
 
 static int bn_check(const char *who, int64_t n, int c) {
@@ -176,7 +209,7 @@ extern "C" int ftx_bn_train_fwd(const float *x, const float *residual, const flo
   double *part = (double *)workspace;
   bn_partial_kernel<FwdOp><<<nb, 256, bn_partial_lds(c), st>>>(x, nullptr, nullptr, nullptr, nullptr, 0, n, c, part);
   bn_finalize_fwd_kernel<<<ceil_div(c, 4), 256, 0, st>>>(part, nb, n, c, eps, momentum, running_mean, running_var, save_mean, save_invstd);
-  bn_apply_fwd_kernel<<<grid_for(n * (c / 4), 256), 256, 0, st>>>(x, residual, gamma, beta, save_mean, save_invstd, n, c, relu, y);
+  bn_apply_fwd_kernel<<<bn_apply_grid(n, c), 256, 0, st>>>(x, residual, gamma, beta, save_mean, save_invstd, n, c, relu, y);
   return check_launch("ftx_bn_train_fwd");
 }
 
@@ -191,7 +224,7 @@ extern "C" int ftx_bn_train_fwd_partials(const float *x, const float *residual, 
   FTX_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && part, "ftx_bn_train_fwd_partials: null pointer");
   hipStream_t st = (hipStream_t)stream;
   bn_finalize_fwd_kernel<<<ceil_div(c, 4), 256, 0, st>>>(part, nb, n, c, eps, momentum, running_mean, running_var, save_mean, save_invstd);
-  bn_apply_fwd_kernel<<<grid_for(n * (c / 4), 256), 256, 0, st>>>(x, residual, gamma, beta, save_mean, save_invstd, n, c, relu, y);
+  bn_apply_fwd_kernel<<<bn_apply_grid(n, c), 256, 0, st>>>(x, residual, gamma, beta, save_mean, save_invstd, n, c, relu, y);
   return check_launch("ftx_bn_train_fwd_partials");
 }
 
@@ -250,38 +283,54 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const double *__re
   }
 }
 
-__global__ void bn_apply_bwd_kernel(const float *__restrict__ gy, const float *__restrict__ x, const float *__restrict__ y,
-                                    const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ invstd,
-                                    const double *__restrict__ sums, int64_t n, int c, int relu, float *__restrict__ gx,
-                                    float *__restrict__ gres) {
+__global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restrict__ gy, const float *__restrict__ x, const float *__restrict__ y,
+                                                           const float *__restrict__ gamma, const float *__restrict__ mean,
+                                                           const float *__restrict__ invstd, const double *__restrict__ sums, int64_t n, int c,
+                                                           int relu, float *__restrict__ gx, float *__restrict__ gres) {
   const int c4 = c >> 2;
-  const int64_t total = n * c4;
+  const int RL = 256 / c4 > 0 ? 256 / c4 : 1;
+  const int cg = threadIdx.x % c4, rl = threadIdx.x / c4;
+  if (rl >= RL) return;
+  const int col = cg * 4;
   const float inv_n = 1.f / (float)n;
-  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    int col = (int)(e % c4) * 4;
-    float4 g4 = *(const float4 *)&gy[e * 4];
-    float4 x4 = *(const float4 *)&x[e * 4];
+  float mu[4], is[4], gm[4], sdy[4], sdyx[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    mu[v] = mean[col + v];
+    is[v] = invstd[col + v];
+    gm[v] = gamma[col + v];
+    sdy[v] = (float)sums[col + v] * inv_n;
+    sdyx[v] = (float)sums[c + col + v] * inv_n;
+  }
+  auto one = [&](int64_t r) {
+    const int64_t o = r * c + col;
+    const float4 g4 = *(const float4 *)&gy[o];
+    const float4 x4 = *(const float4 *)&x[o];
     float dy[4] = {g4.x, g4.y, g4.z, g4.w};
-    float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+    const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
     if (relu) {
-      float4 y4 = *(const float4 *)&y[e * 4];
-      float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+      const float4 y4 = *(const float4 *)&y[o];
+      const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
 #pragma unroll
       for (int v = 0; v < 4; ++v)
         if (!(yv[v] > 0.f)) dy[v] = 0.f;
     }
-    float o[4];
+    float ov[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      float is = invstd[col + v];
-      float xhat = (xv[v] - mean[col + v]) * is;
-      float sdy = (float)sums[col + v] * inv_n;
-      float sdyx = (float)sums[c + col + v] * inv_n;
-      o[v] = gamma[col + v] * is * (dy[v] - sdy - xhat * sdyx);
+      const float xhat = (xv[v] - mu[v]) * is[v];
+      ov[v] = gm[v] * is[v] * (dy[v] - sdy[v] - xhat * sdyx[v]);
     }
-    *(float4 *)&gx[e * 4] = make_float4(o[0], o[1], o[2], o[3]);
-    if (gres) *(float4 *)&gres[e * 4] = make_float4(dy[0], dy[1], dy[2], dy[3]);
+    *(float4 *)&gx[o] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    if (gres) *(float4 *)&gres[o] = make_float4(dy[0], dy[1], dy[2], dy[3]);
+  };
+  const int64_t stride = (int64_t)gridDim.x * RL;
+  int64_t r = (int64_t)blockIdx.x * RL + rl;
+  for (; r + stride < n; r += 2 * stride) {
+    one(r);
+    one(r + stride);
   }
+  if (r < n) one(r);
 }
 
 extern "C" int ftx_bn_train_bwd(const float *grad_y, const float *x, const float *y, const float *gamma, const float *save_mean,
@@ -303,7 +352,6 @@ extern "C" int ftx_bn_train_bwd(const float *grad_y, const float *x, const float
   double *sums = part + (size_t)nb * 2 * c;
   bn_partial_kernel<BwdOp><<<nb, 256, bn_partial_lds(c), st>>>(x, grad_y, relu ? y : nullptr, save_mean, save_invstd, relu, n, c, part);
   bn_finalize_bwd_kernel<<<ceil_div(c, 4), 256, 0, st>>>(part, nb, c, sums, grad_gamma, grad_beta);
-  bn_apply_bwd_kernel<<<grid_for(n * (c / 4), 256), 256, 0, st>>>(grad_y, x, y, gamma, save_mean, save_invstd, sums, n, c, relu, grad_x,
-                                                                   grad_residual);
+  bn_apply_bwd_kernel<<<bn_apply_grid(n, c), 256, 0, st>>>(grad_y, x, y, gamma, save_mean, save_invstd, sums, n, c, relu, grad_x, grad_residual);
   return check_launch("ftx_bn_train_bwd");
 }
