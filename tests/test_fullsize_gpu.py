@@ -122,6 +122,38 @@ def test_one_model_serves_kitti_and_nuscenes_shaped_batches():
         assert (out2[k].cpu() - refs["nuscenes"][k]).abs().max().item() <= TOL, k
 
 
+def test_bf16_forward_mode_on_mixed_full_size_frames():
+    """BASELINE configs[4] at full size on one GPU: the 12-block trunk with bf16 GEMM operands (the "bf16 forward" mode), one model
+    with lift_size="image" taking a whole SemanticKITTI-shaped frame and then a whole NuScenes-shaped frame.  The reference has no bf16
+    mode, so the bar is the fp32 oracle with the looser tolerance stated in tests/test_model_gpu.py: per-point logits within 3e-2."""
+    from fusiontransformer_amd.config import fusion_cfg
+    from fusiontransformer_amd.data.synth import SHAPES, make_batch
+    from fusiontransformer_amd.models.build import build_model
+    from oracle import ft_oracle as O
+    cfg = fusion_cfg("middle")
+    cfg.MODEL.lift_size = "image"
+    torch.manual_seed(4)
+    model, _, _ = build_model(cfg)
+    model = model.cuda().eval()
+    model.image_backbone.backbone.set_bf16(True)
+    sd = {k: v.cpu() for k, v in model.state_dict().items()}
+    for shape, seed in (("kitti", 1), ("nuscenes", 4)):
+        ocfg = dict(cfg.MODEL)
+        ocfg["lift_size"] = (SHAPES[shape]["H"], SHAPES[shape]["W"])
+        oracle = O.build_model(ocfg)
+        oracle.load_state_dict(sd)
+        oracle.eval()
+        batch = make_batch([seed], shape=shape)
+        assert batch["coords"].shape[0] > 18000
+        with torch.no_grad():
+            ref = oracle(oracle_inputs(batch))
+            out = model(product_inputs(batch))
+        err = {k: (out[k].cpu() - ref[k]).abs().max().item() for k in ref}
+        assert max(err.values()) <= 3e-2, (shape, err)
+        assert err["img_seg_logit"] > 1e-6, "bf16 mode did not engage"
+        del oracle
+
+
 def _train_grads(model, pin, seed=0):
     from fusiontransformer_amd.trainer import fusion_losses
     model.zero_grad(set_to_none=True)

@@ -632,3 +632,51 @@ def test_lds_dma_gemm_variant_matches_the_default_kernel(env):
     assert len(res["0"]) == len(res["1"]) == 11
     for a, b in zip(res["0"], res["1"]):
         assert torch.equal(a, b)
+
+
+def test_round2_entry_points_edge_cases(env):
+    """ftx_sorted_rank (absent keys, empty inputs, device-side count smaller than the buffer), the scatter epilogue on a map with a
+    single pair and with a bad scatter index, reduce-with-statistics on one row, and bad arguments failing loudly."""
+    spf, O = env
+    from fusiontransformer_amd import _lib
+    L = _lib.load()
+    # sorted_rank: only the first n_sorted entries count; absent -> -1
+    srt = torch.tensor([2, 5, 9, 11, 10 ** 12, 7, 7], dtype=torch.int64, device="cuda")     # last two are beyond the count
+    cnt = torch.tensor([5], dtype=torch.int32, device="cuda")
+    q = torch.tensor([5, 7, 10 ** 12, 1, 11, 2], dtype=torch.int64, device="cuda")
+    assert spf.sorted_rank(srt, cnt, q).cpu().tolist() == [1, -1, 4, -1, 3, 0]
+    assert spf.sorted_rank(srt, cnt, q[:0]).shape[0] == 0
+    zero = torch.tensor([0], dtype=torch.int32, device="cuda")
+    assert spf.sorted_rank(srt, zero, q).cpu().tolist() == [-1] * 6
+    with pytest.raises(ValueError):
+        spf.sorted_rank(srt.int(), cnt, q)
+    # one-launch scatter GEMM: rows not named by `scatter` stay untouched, an out-of-range destination is skipped
+    a = torch.randn(3, 8, device="cuda")
+    w = torch.randn(1, 8, 4, device="cuda")
+    gather = torch.tensor([2, 0], dtype=torch.int32, device="cuda")
+    scatter = torch.tensor([1, 99], dtype=torch.int32, device="cuda")
+    koff = torch.tensor([0, 2], dtype=torch.int32, device="cuda")
+    out = torch.full((3, 4), 7.0, device="cuda")
+    rc = L.ftx_spconv_pairs_gemm_scatter(a.data_ptr(), 3, gather.data_ptr(), scatter.data_ptr(), w.data_ptr(), 0, koff.data_ptr(), 2, 8, 4, 1,
+                                         out.data_ptr(), 3, spf.stream())
+    assert rc == 0
+    exp = torch.full((3, 4), 7.0)
+    exp[1] = (a[2] @ w[0]).cpu()
+    np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-6)
+    assert L.ftx_spconv_pairs_gemm_scatter(a.data_ptr(), 3, gather.data_ptr(), 0, w.data_ptr(), 0, koff.data_ptr(), 2, 8, 4, 1, out.data_ptr(), 3, spf.stream()) != 0
+    assert b"null" in L.ftx_last_error()
+    # reduce + statistics on a single output row with a single pair
+    tmp = torch.randn(1, 8, device="cuda")
+    pos = torch.full((27, 1), -1, dtype=torch.int32, device="cuda")
+    pos[13, 0] = 0
+    nb = int(L.ftx_spconv_reduce_stats_blocks(1, 8))
+    part = torch.empty((nb, 2, 8), dtype=torch.float64, device="cuda")
+    o1 = torch.empty(1, 8, device="cuda")
+    assert L.ftx_spconv_reduce_stats(tmp.data_ptr(), pos.data_ptr(), 1, 8, 27, o1.data_ptr(), part.data_ptr(), nb, spf.stream()) == 0
+    assert torch.equal(o1, tmp)
+    np.testing.assert_allclose(part.sum(0)[0].cpu().numpy(), tmp[0].double().cpu().numpy(), rtol=0, atol=0)
+    np.testing.assert_allclose(part.sum(0)[1].cpu().numpy(), (tmp[0].double() ** 2).cpu().numpy(), rtol=1e-15)
+    assert L.ftx_spconv_reduce_stats(tmp.data_ptr(), pos.data_ptr(), 1, 8, 27, o1.data_ptr(), part.data_ptr(), nb + 1, spf.stream()) != 0
+    # the fused loss refuses an unknown mix
+    with pytest.raises(ValueError):
+        spf.fusion_loss({}, torch.zeros(1), None, 0.1, False, mix="other")
