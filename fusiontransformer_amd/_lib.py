@@ -56,6 +56,8 @@ SIGNATURES = {
     "ftx_sample_down_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ftx_spconv_pairs_gemm": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "ftx_spconv_pairs_gemm_scatter": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
+    "ftx_spconv_set_gemm_variant": (None, [_i32]),
+    "ftx_spconv_get_gemm_variant": (_i32, []),
     "ftx_spconv_set_split": (None, [_i32]),
     "ftx_spconv_get_split": (_i32, []),
     "ftx_rows_gemm": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),

@@ -362,6 +362,7 @@ static void launch_pairs_gemm(int nt, dim3 grid, hipStream_t st, const float *A,
 
 #include "ftx_spconv_dma.h"
 #include "ftx_spconv_split.h"
+#include "ftx_spconv_pc.h"
 
 // Arithmetic of the matrix products of the sparse convolution: 0 = exact-f32 MFMA (default), 1 = three-way bf16 operand split on the
 // bf16 matrix cores, f32-equivalent accuracy (ftx_spconv_split.h).  Process-wide switch; FTX_SPCONV_SPLIT=1 sets the initial value.
@@ -372,6 +373,38 @@ static bool split_on() {
 }
 extern "C" void ftx_spconv_set_split(int32_t on) { g_split = on ? 1 : 0; }
 extern "C" int32_t ftx_spconv_get_split(void) { return split_on() ? 1 : 0; }
+
+// Producer / consumer kernel (ftx_spconv_pc.h): whole 32-channel chunks and whole column tiles only.  FTX_GEMM_PC=1 selects it.
+// Pair-GEMM kernel variant: 0 register-staged tile kernel (default), 1 LDS-DMA tile kernel, 2 producer / consumer kernel.  All three are
+// exact-f32 and bit-identical; ftx_spconv_set_gemm_variant() switches at run time, FTX_GEMM_DMA=1 / FTX_GEMM_PC=1 set the initial value.
+static int g_gemm_variant = -1;
+static int gemm_variant() {
+  if (g_gemm_variant < 0) {
+    int v = 0;
+    if (getenv("FTX_GEMM_DMA") && atoi(getenv("FTX_GEMM_DMA"))) v = 1;
+    if (getenv("FTX_GEMM_PC") && atoi(getenv("FTX_GEMM_PC"))) v = 2;
+    g_gemm_variant = v;
+  }
+  return g_gemm_variant;
+}
+extern "C" void ftx_spconv_set_gemm_variant(int32_t v) { g_gemm_variant = (v >= 0 && v <= 2) ? v : 0; }
+extern "C" int32_t ftx_spconv_get_gemm_variant(void) { return gemm_variant(); }
+
+static bool gemm_use_pc(int64_t n_rows, int ca, int co, int nt) {
+  return gemm_variant() == 2 && n_rows >= 1 && ca % 32 == 0 && co % (32 * nt) == 0;
+}
+static unsigned pc_blocks() {
+  int dev = 0, n = 0;
+  static int cus = 0;
+  if (cus == 0) {
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) {
+      (void)hipGetLastError();
+      n = 256;
+    }
+    cus = n;
+  }
+  return (unsigned)cus;
+}
 
 static int gemm_nt(int co) {
   int nt = co >= 128 ? 4 : (co + 31) / 32;
@@ -391,9 +424,9 @@ static int gemm_rt(int64_t n_pairs, int kvol, int ca, int co) {
 // 4-channel stem, the class heads) stays on the register-staged kernel.  Measured on MI355X over the 20 layers of
 // tools/bench_spconv.py it ties the register-staged kernel (891 vs 903 us forward, 911 vs 893 us dgrad: 3-5 % faster on
 // the deep levels, 2-3 % slower on level 0), so it is an opt-in tuning alternative: FTX_GEMM_DMA=1.
+static int gemm_variant();
 static bool gemm_use_dma(int64_t n_rows, int ca, int co, int nt) {
-  static const int enabled = getenv("FTX_GEMM_DMA") ? atoi(getenv("FTX_GEMM_DMA")) : 0;
-  return enabled && n_rows >= 1 && ca % 32 == 0 && co % (32 * nt) == 0;
+  return gemm_variant() == 1 && n_rows >= 1 && ca % 32 == 0 && co % (32 * nt) == 0;
 }
 
 extern "C" int ftx_spconv_pairs_gemm(const float *A, int64_t rows_a, const int32_t *gather, const float *W, int32_t w_transposed,
@@ -409,6 +442,9 @@ extern "C" int ftx_spconv_pairs_gemm(const float *A, int64_t rows_a, const int32
   if (split_on()) {
     dim3 g1((unsigned)(ceil_div(n_pairs, TILE_P) + kvol), grid.y);
     split::launch(nt, g1, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0, nullptr, 0);
+  } else if (gemm_use_pc(n_pairs, ca, co, nt)) {
+    FTX_REQUIRE(pc::dispatch(nt, pc_blocks(), st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0, nullptr, 0) == 0,
+                "ftx_spconv_pairs_gemm: could not configure the producer / consumer kernel");
   } else if (rt == 1 && gemm_use_dma(n_pairs, ca, co, nt)) {
     FTX_REQUIRE(dma::dispatch(nt, grid, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0) == 0,
                 "ftx_spconv_pairs_gemm: could not configure the LDS-DMA kernel");
@@ -435,6 +471,9 @@ extern "C" int ftx_spconv_pairs_gemm_scatter(const float *A, int64_t rows_a, con
   dim3 grid((unsigned)(ceil_div(n_pairs, TILE_P) + kvol), (unsigned)ceil_div(co, 32 * nt));
   if (split_on())
     split::launch(nt, grid, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, out, nullptr, 0, scatter, rows_out);
+  else if (gemm_use_pc(n_pairs, ca, co, nt))
+    FTX_REQUIRE(pc::dispatch(nt, pc_blocks(), st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, out, nullptr, 0, scatter, rows_out) == 0,
+                "ftx_spconv_pairs_gemm_scatter: could not configure the producer / consumer kernel");
   else
     launch_pairs_gemm<1>(nt, grid, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, out, nullptr, 0, scatter, rows_out);
   return check_launch("ftx_spconv_pairs_gemm_scatter");

@@ -176,6 +176,12 @@ int ftx_spconv_pairs_gemm(const float *A, int64_t rows_a, const int32_t *gather,
  * named by scatter are left untouched.  Replaces pairs_gemm + reduce (no tmp round trip). */
 int ftx_spconv_pairs_gemm_scatter(const float *A, int64_t rows_a, const int32_t *gather, const int32_t *scatter, const float *W, int32_t w_transposed, const int32_t *koff, int64_t n_pairs, int32_t ca, int32_t co, int32_t kvol, float *out, int64_t rows_out, void *stream);
 
+/* Kernel variant of the pair GEMM (process-wide switch, initial value from FTX_GEMM_DMA=1 / FTX_GEMM_PC=1): 0 register-staged tile kernel
+ * (default), 1 LDS-DMA tile kernel, 2 persistent producer / consumer kernel (loader waves fill an LDS ring ahead of the MFMA waves).
+ * All three compute the same exact-f32 MFMA sequence: bit-identical results. */
+void ftx_spconv_set_gemm_variant(int32_t variant);
+int32_t ftx_spconv_get_gemm_variant(void);
+
 /* Arithmetic of the sparse-convolution matrix products (process-wide switch, initial value from FTX_SPCONV_SPLIT):
  *   0 (default)  exact-f32 MFMA (v_mfma_f32_32x32x2_f32): bit-for-bit an f32 fma chain;
  *   1            every f32 operand split in-kernel into three bf16 terms (exact), six bf16-MFMA partial products accumulated in

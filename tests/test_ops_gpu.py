@@ -634,6 +634,61 @@ def test_lds_dma_gemm_variant_matches_the_default_kernel(env):
         assert torch.equal(a, b)
 
 
+def test_producer_consumer_gemm_variant_is_bit_identical(env):
+    """ftx_spconv_set_gemm_variant(2): the persistent producer / consumer pair GEMM (loader waves fill an LDS ring, two groups of MFMA
+    waves alternate over the workgroup's tiles, slot hand-over by FULL / FREE counters in LDS) against the default tile kernel: same
+    MFMA sequence per tile, so bit-identical -- forward and data-gradient weight layouts, ragged last tiles, tiny maps (fewer tiles than
+    workgroups), 1 / 4 / 8 / 12 chunks per tile, two column tiles, the scatter epilogue, whole model layers at the bench's size."""
+    spf, O = env
+    from fusiontransformer_amd import _lib
+    from fusiontransformer_amd.data.synth import make_batch
+    from fusiontransformer_amd.models.utils import initial_voxelize
+    from fusiontransformer_amd.sparse import PointTensor
+    L = _lib.load()
+    torch.manual_seed(0)
+    b = make_batch([0, 1], max_points=9000)
+    z = PointTensor(torch.from_numpy(b["feats"]).cuda(), torch.from_numpy(b["coords"]).float().cuda())
+    cm = initial_voxelize(z, 1, 1).cm
+    cases = [(3, 1, 1, 32, 32), (3, 1, 1, 128, 96), (3, 1, 1, 64, 128), (2, 1, 2, 32, 64), (3, 2, 1, 96, 256), (3, 2, 1, 384, 256), (3, 4, 1, 256, 256),
+             (2, 4, 2, 128, 128), (3, 16, 1, 256, 256)]
+    cm.kernel_map(2, 2, 2); cm.kernel_map(2, 8, 2)
+    try:
+        for ks, cur, st, ca, co in cases:
+            km = cm.kernel_map(ks, cur, st)
+            A = torch.randn(km.n_in, ca, device="cuda")
+            for wt in (0, 1):
+                W = torch.randn(ks ** 3, *((co, ca) if wt else (ca, co)), device="cuda") * 0.1
+                outs = []
+                for variant in (0, 2):
+                    L.ftx_spconv_set_gemm_variant(variant)
+                    assert L.ftx_spconv_get_gemm_variant() == variant
+                    tmp = torch.full((km.n_pairs, co), float("nan"), device="cuda")
+                    rc = L.ftx_spconv_pairs_gemm(A.data_ptr(), km.n_in, km.pair_in.data_ptr(), W.data_ptr(), wt, km.koff.data_ptr(), km.n_pairs, ca, co,
+                                                 ks ** 3, tmp.data_ptr(), spf.stream())
+                    assert rc == 0
+                    outs.append(tmp)
+                torch.cuda.synchronize()
+                assert torch.equal(outs[0], outs[1]), (ks, cur, st, ca, co, wt)
+            if ks == 2:   # scatter epilogue: data gradient of the strided conv
+                G = torch.randn(km.n_out, co, device="cuda")
+                Wt = torch.randn(8, ca, co, device="cuda") * 0.1
+                outs = []
+                for variant in (0, 2):
+                    L.ftx_spconv_set_gemm_variant(variant)
+                    outs.append(spf._spconv_direct(G, Wt, km.pair_out, km.pair_in, km.koff, km.n_pairs, km.n_in, ca, 1))
+                assert torch.equal(outs[0], outs[1])
+        # repeated launches reuse nothing across calls (the ring counters start at zero in every launch)
+        L.ftx_spconv_set_gemm_variant(2)
+        km = cm.kernel_map(3, 1, 1)
+        A = torch.randn(km.n_in, 64, device="cuda"); W = torch.randn(27, 64, 64, device="cuda")
+        t1 = torch.empty(km.n_pairs, 64, device="cuda"); t2 = torch.empty_like(t1)
+        for t in (t1, t2):
+            L.ftx_spconv_pairs_gemm(A.data_ptr(), km.n_in, km.pair_in.data_ptr(), W.data_ptr(), 0, km.koff.data_ptr(), km.n_pairs, 64, 64, 27, t.data_ptr(), spf.stream())
+        assert torch.equal(t1, t2)
+    finally:
+        L.ftx_spconv_set_gemm_variant(0)
+
+
 def test_round2_entry_points_edge_cases(env):
     """ftx_sorted_rank (absent keys, empty inputs, device-side count smaller than the buffer), the scatter epilogue on a map with a
     single pair and with a bad scatter index, reduce-with-statistics on one row, and bad arguments failing loudly."""
