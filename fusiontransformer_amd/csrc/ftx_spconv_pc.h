@@ -28,16 +28,16 @@ constexpr int A_BYTES = TILE * BK * 4;
 constexpr int RING = 4;
 constexpr int SPIN_LIMIT = 1 << 17;   // ~25 M cycles: three orders of magnitude above any legitimate wait
 
-__device__ __forceinline__ unsigned ld_flag(const unsigned *p) { return *(const volatile unsigned *)p; }
-
-// Blocks until *p >= target (bounded: a protocol error must not hang the GPU; the result is then wrong and the tests say so).
-__device__ __forceinline__ void wait_flag(const unsigned *p, unsigned target) {
-  int spins = 0;
-  while (ld_flag(p) < target) {
-    __builtin_amdgcn_s_sleep(1);
-    if (++spins > SPIN_LIMIT) break;
-  }
-}
+// The hand-over counters live in LDS and must be read as LDS (ds_read), never through a generic pointer: a flat load counts on vmcnt as
+// well, so a poll would drain every LDS-DMA in flight.  Hence macros over the __shared__ arrays instead of functions taking pointers.
+#define FTX_PC_WAIT(arr, idx, target)                                   \
+  do {                                                                  \
+    int spins_ = 0;                                                     \
+    while (__hip_atomic_load(&(arr)[(idx)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (target)) { \
+      __builtin_amdgcn_s_sleep(1);                                      \
+      if (++spins_ > SPIN_LIMIT) break; /* bounded: never hang the GPU */ \
+    }                                                                   \
+  } while (0)
 
 // tile index (over all offsets, then column tiles) -> offset, first pair, pair count, column tile.  Every wave computes it by itself
 // from a 64-lane scan of the per-offset tile counts; returns false past the last tile.
@@ -91,7 +91,9 @@ template <int NT>
 __global__ __launch_bounds__(768) void pairs_gemm_pc_kernel(const float *__restrict__ A, int64_t rows_a, const int32_t *__restrict__ gather,
                                                             const float *__restrict__ W, int w_transposed, const int32_t *__restrict__ koff,
                                                             int ca, int co, int kvol, float *__restrict__ tmp, const float *__restrict__ bias,
-                                                            int64_t n_dense, const int32_t *__restrict__ scatter, int64_t rows_out) {
+                                                            int64_t n_dense, const int32_t *__restrict__ scatter, int64_t rows_out, int debug) {
+  // debug (measurement aid, FTX_PC_DEBUG): 1 = consumers skip the MFMAs (memory + hand-over only), 2 = loaders skip the DMAs (compute +
+  // hand-over only, results are garbage), 0 = the product
   constexpr int BN = 32 * NT;
   constexpr int W_BYTES = BN * BK * 4;
   constexpr int STAGE = A_BYTES + W_BYTES;
@@ -149,22 +151,24 @@ __global__ __launch_bounds__(768) void pairs_gemm_pc_kernel(const float *__restr
       }
       for (int c = 0; c < steps; ++c, ++q) {
         const unsigned s = q % RING, fill = q / RING;
-        if (ld_flag(&s_free[s]) < 4u * fill) {
+        if (__hip_atomic_load(&s_free[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * fill) {
           // about to wait for the consumers: first make every chunk already issued visible to them (they may be waiting for exactly those)
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           for (; signalled < q; ++signalled)
-            if (lane == 0) atomicAdd(&s_full[signalled % RING], 1u);
-          wait_flag(&s_free[s], 4u * fill);
+            if (lane == 0) __hip_atomic_fetch_add(&s_full[signalled % RING], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          FTX_PC_WAIT(s_free, s, 4u * fill);
         }
         const unsigned sa = lds0 + s * STAGE;
+        if (debug != 2) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) dma::glds16(a_src[u] + c * BK, sa + (wave * 32 + u * 8) * 128);
+          for (int u = 0; u < 4; ++u) dma::glds16(a_src[u] + c * BK, sa + (wave * 32 + u * 8) * 128);
 #pragma unroll
-        for (int u = 0; u < NT; ++u) dma::glds16(w_src[u] + (int64_t)c * w_step, sa + A_BYTES + (u * 4 + wave) * 1024);
+          for (int u = 0; u < NT; ++u) dma::glds16(w_src[u] + (int64_t)c * w_step, sa + A_BYTES + (u * 4 + wave) * 1024);
+        }
         // at most RING-1 chunks stay in flight: when RING are unpublished the oldest has landed -> publish it
         if (q + 1 - signalled >= (unsigned)RING) {
           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_CHUNK * (RING - 1)) : "memory");
-          if (lane == 0) atomicAdd(&s_full[signalled % RING], 1u);
+          if (lane == 0) __hip_atomic_fetch_add(&s_full[signalled % RING], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           ++signalled;
         }
       }
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(768) void pairs_gemm_pc_kernel(const float *__restr
     // drain: publish the chunks still in flight
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (; signalled < q; ++signalled)
-      if (lane == 0) atomicAdd(&s_full[signalled % RING], 1u);
+      if (lane == 0) __hip_atomic_fetch_add(&s_full[signalled % RING], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return;
   }
 
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(768) void pairs_gemm_pc_kernel(const float *__restr
     for (int c = 0; c < steps; ++c) {
       const unsigned q = (unsigned)j * steps + c;
       const unsigned s = q % RING, fill = q / RING;
-      wait_flag(&s_full[s], 4u * (fill + 1));
+      FTX_PC_WAIT(s_full, s, 4u * (fill + 1));
       const char *sa = smem + s * STAGE;
       const char *sw = sa + A_BYTES;
       const char *ap = sa + cw * 32 * 128;
@@ -226,13 +230,18 @@ __global__ __launch_bounds__(768) void pairs_gemm_pc_kernel(const float *__restr
         } else {
           // the last fragments of this slot are in registers once lgkmcnt drains: hand the slot back before the last MFMAs
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (lane == 0) atomicAdd(&s_free[s], 1u);
+          if (lane == 0) __hip_atomic_fetch_add(&s_free[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        if (debug != 1) {
 #pragma unroll
-        for (int ss = 0; ss < 4; ++ss)
+          for (int ss = 0; ss < 4; ++ss)
 #pragma unroll
-          for (int jj = 0; jj < NT; ++jj)
-            acc[jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[t & 1][jj][ss], af[t & 1][ss], acc[jj], 0, 0, 0);
+            for (int jj = 0; jj < NT; ++jj)
+              acc[jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[t & 1][jj][ss], af[t & 1][ss], acc[jj], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < NT; ++jj) acc[jj][0] += bf[t & 1][jj][0] + af[t & 1][0];
+        }
       }
     }
 
@@ -275,7 +284,8 @@ static int launch(unsigned blocks, hipStream_t st, const float *A, int64_t rows_
     if (hipFuncSetAttribute((const void *)pairs_gemm_pc_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
     configured = true;
   }
-  pairs_gemm_pc_kernel<NT><<<blocks, 768, LDS, st>>>(A, rows_a, gather, W, wT, koff, ca, co, kvol, tmp, bias, n_dense, scatter, rows_out);
+  static const int debug = getenv("FTX_PC_DEBUG") ? atoi(getenv("FTX_PC_DEBUG")) : 0;
+  pairs_gemm_pc_kernel<NT><<<blocks, 768, LDS, st>>>(A, rows_a, gather, W, wT, koff, ca, co, kvol, tmp, bias, n_dense, scatter, rows_out, debug);
   return 0;
 }
 

@@ -651,7 +651,8 @@ def test_producer_consumer_gemm_variant_is_bit_identical(env):
     cm = initial_voxelize(z, 1, 1).cm
     cases = [(3, 1, 1, 32, 32), (3, 1, 1, 128, 96), (3, 1, 1, 64, 128), (2, 1, 2, 32, 64), (3, 2, 1, 96, 256), (3, 2, 1, 384, 256), (3, 4, 1, 256, 256),
              (2, 4, 2, 128, 128), (3, 16, 1, 256, 256)]
-    cm.kernel_map(2, 2, 2); cm.kernel_map(2, 8, 2)
+    for s_ in (1, 2, 4, 8):          # walk down: every level's coordinates come from the strided map above it
+        cm.kernel_map(2, s_, 2)
     try:
         for ks, cur, st, ca, co in cases:
             km = cm.kernel_map(ks, cur, st)
