@@ -26,6 +26,7 @@ constexpr int TILE = 128;
 constexpr int BK = 32;
 constexpr int A_BYTES = TILE * BK * 4;
 constexpr int RING = 4;
+constexpr int TR = 16;     // tile descriptors kept in LDS: a loader is never more than 2 RING + 1 tiles ahead of a consumer's epilogue
 constexpr int SPIN_LIMIT = 1 << 17;   // ~25 M cycles: three orders of magnitude above any legitimate wait
 
 // The hand-over counters live in LDS and must be read as LDS (ds_read), never through a generic pointer: a flat load counts on vmcnt as
@@ -99,6 +100,12 @@ __global__ __launch_bounds__(768) void pairs_gemm_pc_kernel(const float *__restr
   constexpr int STAGE = A_BYTES + W_BYTES;
   extern __shared__ __attribute__((aligned(1024))) char smem[];   // [RING stages][A image | W image]
   __shared__ unsigned s_full[RING], s_free[RING];
+  // Per-tile descriptors written by the loaders (which have the tile's indices in hand anyway), read by the consumers: a consumer wave
+  // never issues a global LOAD -- its tile lookup and destination rows come from here -- so nothing but the ring stands between two of
+  // its MFMA phases except its own stores.  s_drow: destination row of every pair of the tile; -1 = no store; <= -2 encodes "store a
+  // zero row at -2 - value" (a pair whose source index was out of range).
+  __shared__ int s_desc[TR][4];
+  __shared__ int s_drow[TR][TILE];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
 
   const int tid = threadIdx.x;
@@ -149,6 +156,32 @@ __global__ __launch_bounds__(768) void pairs_gemm_pc_kernel(const float *__restr
           w_src[u] = Wk + (int64_t)(n0 + n) * ca + piece * 4;
         }
       }
+      {
+        const int ts = j % TR;
+        if (wave == 0 && lane == 0) {
+          s_desc[ts][0] = ti.k;
+          s_desc[ts][1] = ti.p0;
+          s_desc[ts][2] = ti.cnt;
+          s_desc[ts][3] = n0;
+        }
+        if (lane < 32) {
+          const int r = wave * 32 + lane;
+          int d = -1;
+          if (r < ti.cnt) {
+            const int64_t p = ti.p0 + r;
+            bool zero = false;
+            if (gather) {
+              const int32_t sidx = gather[p];
+              zero = sidx < 0 || sidx >= rows_a;
+            }
+            int64_t dr = scatter ? (int64_t)scatter[p] : p;
+            if (scatter && (dr < 0 || dr >= rows_out)) dr = -1;
+            d = dr < 0 ? -1 : (zero ? (int)(-2 - dr) : (int)dr);
+          }
+          s_drow[ts][r] = d;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // descriptor in LDS before this wave publishes the tile's first chunk
+      }
       for (int c = 0; c < steps; ++c, ++q) {
         const unsigned s = q % RING, fill = q / RING;
         if (__hip_atomic_load(&s_free[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * fill) {
@@ -188,9 +221,7 @@ __global__ __launch_bounds__(768) void pairs_gemm_pc_kernel(const float *__restr
   for (int t = 0; t < 4; ++t) frag_off[t] = l31 * 128 + (((2 * t + half) ^ fsw) << 4);
 
   for (int j = g; (int)(blockIdx.x + j * gridDim.x) < total; j += 2) {
-    TileInfo ti;
-    if (!tile_lookup(blockIdx.x + j * gridDim.x, koff, kvol, col_tiles, n_dense, lane, ti)) break;
-    const int n0 = ti.ct * BN;
+    const int ts = j % TR;
     f32x16 acc[NT];
 #pragma unroll
     for (int jj = 0; jj < NT; ++jj)
@@ -245,17 +276,11 @@ __global__ __launch_bounds__(768) void pairs_gemm_pc_kernel(const float *__restr
       }
     }
 
-    const int row = cw * 32 + l31;
-    int64_t drow = row < ti.cnt ? ti.p0 + row : -1;
-    bool zero = false;
-    if (gather != nullptr && drow >= 0) {
-      const int32_t sidx = gather[drow];
-      zero = sidx < 0 || sidx >= rows_a;
-    }
-    if (scatter != nullptr && drow >= 0) {
-      drow = scatter[drow];
-      if (drow >= rows_out) drow = -1;
-    }
+    // the tile's first chunk was published after its descriptor was written: it is visible now
+    const int n0 = s_desc[ts][3];
+    const int d = s_drow[ts][cw * 32 + l31];
+    const bool zero = d <= -2;
+    const int64_t drow = zero ? (int64_t)(-2 - d) : (int64_t)d;
     if (drow >= 0) {
       float *dst = tmp + drow * co;
 #pragma unroll
