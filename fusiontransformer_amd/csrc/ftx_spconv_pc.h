@@ -45,10 +45,12 @@ constexpr int SPIN_LIMIT = 1 << 17;   // ~25 M cycles: three orders of magnitude
 struct TileInfo {
   int k, p0, cnt, ct;
 };
-__device__ __forceinline__ bool tile_lookup(int t, const int32_t *__restrict__ koff, int kvol, int col_tiles, int64_t n_dense, int lane, TileInfo &ti) {
+// kc / kb: this lane's offset (lane < kvol) pair count and first pair, loaded ONCE per wave: the lookup itself is shuffles only, so a
+// loader can look a tile ahead without touching memory.
+__device__ __forceinline__ bool tile_lookup(int t, int kc, int kb, bool dense, int col_tiles, int64_t n_dense, int lane, TileInfo &ti) {
   const int pt = t / col_tiles;
   ti.ct = t - pt * col_tiles;
-  if (koff == nullptr) {
+  if (dense) {
     const int64_t left = n_dense - (int64_t)pt * TILE;
     if (left <= 0) return false;
     ti.k = 0;
@@ -56,8 +58,7 @@ __device__ __forceinline__ bool tile_lookup(int t, const int32_t *__restrict__ k
     ti.cnt = left > TILE ? TILE : (int)left;
     return true;
   }
-  int c = (lane < kvol) ? koff[lane + 1] - koff[lane] : 0;
-  int nt = (c + TILE - 1) / TILE;
+  int nt = (kc + TILE - 1) / TILE;
   int incl = nt;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -65,27 +66,34 @@ __device__ __forceinline__ bool tile_lookup(int t, const int32_t *__restrict__ k
     if (lane >= off) incl += v;
   }
   const int excl = incl - nt;
-  const bool mine = (lane < kvol) && pt >= excl && pt < incl;
+  const bool mine = pt >= excl && pt < incl;   // lanes >= kvol have nt == 0: never "mine"
   const unsigned long long m = __ballot(mine);
   if (m == 0ull) return false;
   const int src = __ffsll((long long)m) - 1;
   const int tt = pt - __shfl(excl, src, 64);
-  const int cc = __shfl(c, src, 64);
+  const int cc = __shfl(kc, src, 64);
   const int left = cc - tt * TILE;
   ti.k = src;
-  ti.p0 = __shfl((lane < kvol) ? koff[lane] : 0, src, 64) + tt * TILE;
+  ti.p0 = __shfl(kb, src, 64) + tt * TILE;
   ti.cnt = left > TILE ? TILE : left;
   return true;
 }
 
-// number of (pair tile, column tile) tiles of the launch
-__device__ __forceinline__ int tile_total(const int32_t *__restrict__ koff, int kvol, int col_tiles, int64_t n_dense, int lane) {
-  if (koff == nullptr) return (int)ceil_div(n_dense, (int64_t)TILE) * col_tiles;
-  int c = (lane < kvol) ? koff[lane + 1] - koff[lane] : 0;
-  int nt = (c + TILE - 1) / TILE;
+__device__ __forceinline__ int tile_total(int kc, bool dense, int col_tiles, int64_t n_dense) {
+  if (dense) return (int)ceil_div(n_dense, (int64_t)TILE) * col_tiles;
+  int nt = (kc + TILE - 1) / TILE;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) nt += __shfl_xor(nt, off, 64);
   return nt * col_tiles;
+}
+
+// one dword per lane, global -> LDS at lds_dst + 4 * lane (index prefetch of the loaders: counted on vmcnt, no VGPR, no compiler-inserted wait)
+__device__ __forceinline__ void glds4(const void *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
 }
 
 template <int NT>
@@ -106,6 +114,9 @@ __global__ __launch_bounds__(768) void pairs_gemm_pc_kernel(const float *__restr
   // zero row at -2 - value" (a pair whose source index was out of range).
   __shared__ int s_desc[TR][4];
   __shared__ int s_drow[TR][TILE];
+  // index prefetch of the loaders: [buffer][loader wave][0..31 gather index, 32..63 scatter index of the wave's 32 pairs], fetched by
+  // LDS-DMA one tile ahead so that the loader loop contains no global load the compiler would wait for
+  __shared__ __attribute__((aligned(256))) int s_idx[2][4][64];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
 
   const int tid = threadIdx.x;
@@ -119,7 +130,13 @@ __global__ __launch_bounds__(768) void pairs_gemm_pc_kernel(const float *__restr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col_tiles = co / BN;
   const int steps = ca / BK;
-  const int total = tile_total(koff, kvol, col_tiles, n_dense, lane);
+  const bool dense = (koff == nullptr);
+  int kc = 0, kb = 0;
+  if (!dense && lane < kvol) {
+    kb = koff[lane];
+    kc = koff[lane + 1] - kb;
+  }
+  const int total = tile_total(kc, dense, col_tiles, n_dense);
 
   if (wave < 4) {
     // ------------------------------------------------------------------ loader wave `wave`: rows [32 wave, 32 wave + 32) of A, pieces wave, wave+4, ... of W
@@ -127,17 +144,36 @@ __global__ __launch_bounds__(768) void pairs_gemm_pc_kernel(const float *__restr
     unsigned q = 0;   // chunks issued by this workgroup so far (same sequence in every wave)
     unsigned signalled = 0;
     constexpr int PER_CHUNK = 4 + NT;   // DMA instructions per chunk and loader wave
-    for (int j = 0; (int)(blockIdx.x + j * gridDim.x) < total; ++j) {
-      TileInfo ti;
-      if (!tile_lookup(blockIdx.x + j * gridDim.x, koff, kvol, col_tiles, n_dense, lane, ti)) break;
+    const unsigned idx0 = (unsigned)(size_t)(__attribute__((address_space(3))) int *)&s_idx[0][0][0];
+    auto fetch_idx = [&](const TileInfo &t, int buf) {
+      // lanes 0..31: gather index of pair 32 wave + lane, lanes 32..63: its scatter index (rows past the tile's end re-read pair p0)
+      if (gather == nullptr) return;
+      const int r = wave * 32 + (lane & 31);
+      const int64_t p = t.p0 + (r < t.cnt ? r : 0);
+      const int32_t *src = (lane < 32 || scatter == nullptr) ? gather + p : scatter + p;
+      glds4(src, idx0 + (unsigned)((buf * 4 + wave) * 64 * 4));
+    };
+    TileInfo ti, tn;
+    bool have = (int)blockIdx.x < total && tile_lookup(blockIdx.x, kc, kb, dense, col_tiles, n_dense, lane, ti);
+    if (have) {
+      fetch_idx(ti, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    for (int j = 0; have; ++j) {
+      const int buf = j & 1;
+      // look one tile ahead and start fetching its indices: they are older than every chunk DMA of tile j, so they have landed when the
+      // counted wait at the top of the next trip has let all but the youngest chunk DMAs retire
+      const int tnext = blockIdx.x + (j + 1) * gridDim.x;
+      const bool have_next = tnext < total && tile_lookup(tnext, kc, kb, dense, col_tiles, n_dense, lane, tn);
+      if (have_next) fetch_idx(tn, buf ^ 1);
       const int n0 = ti.ct * BN;
       const float *Wk = W + (int64_t)ti.k * ca * co;
       const float *a_src[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int r = wave * 32 + u * 8 + (lane >> 3);
-        int64_t row = ti.p0 + (r < ti.cnt ? r : 0);     // rows past the tile's end: any valid row (never stored)
-        if (gather) row = gather[row];
+        const int rl = u * 8 + (lane >> 3);            // row inside this wave's 32-row group
+        const int r = wave * 32 + rl;
+        int64_t row = gather ? (int64_t)s_idx[buf][wave][rl] : (int64_t)(ti.p0 + (r < ti.cnt ? r : 0));
         if (row < 0 || row >= rows_a) row = 0;
         const int piece = (lane & 7) ^ ((r >> 1) & 7);
         a_src[u] = A + row * ca + piece * 4;
@@ -170,12 +206,15 @@ __global__ __launch_bounds__(768) void pairs_gemm_pc_kernel(const float *__restr
           if (r < ti.cnt) {
             const int64_t p = ti.p0 + r;
             bool zero = false;
+            int64_t dr = p;
             if (gather) {
-              const int32_t sidx = gather[p];
+              const int32_t sidx = s_idx[buf][wave][lane];
               zero = sidx < 0 || sidx >= rows_a;
+              if (scatter) {
+                dr = s_idx[buf][wave][32 + lane];
+                if (dr < 0 || dr >= rows_out) dr = -1;
+              }
             }
-            int64_t dr = scatter ? (int64_t)scatter[p] : p;
-            if (scatter && (dr < 0 || dr >= rows_out)) dr = -1;
             d = dr < 0 ? -1 : (zero ? (int)(-2 - dr) : (int)dr);
           }
           s_drow[ts][r] = d;
@@ -204,6 +243,15 @@ __global__ __launch_bounds__(768) void pairs_gemm_pc_kernel(const float *__restr
           if (lane == 0) __hip_atomic_fetch_add(&s_full[signalled % RING], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           ++signalled;
         }
+      }
+      // next tile: its indices were fetched before this tile's chunk DMAs; all but the youngest min(steps, RING-1) chunks' DMAs retired
+      // means they have landed (vmcnt retires in order)
+      have = have_next;
+      ti = tn;
+      if (have) {
+        if (steps >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_CHUNK * 3) : "memory");
+        else if (steps == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_CHUNK * 2) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_CHUNK * 1) : "memory");
       }
     }
     // drain: publish the chunks still in flight
