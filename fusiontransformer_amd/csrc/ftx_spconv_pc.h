@@ -102,7 +102,8 @@ __global__ __launch_bounds__(768) void pairs_gemm_pc_kernel(const float *__restr
                                                             int ca, int co, int kvol, float *__restrict__ tmp, const float *__restrict__ bias,
                                                             int64_t n_dense, const int32_t *__restrict__ scatter, int64_t rows_out, int debug) {
   // debug (measurement aid, FTX_PC_DEBUG): 1 = consumers skip the MFMAs (memory + hand-over only), 2 = loaders skip the DMAs (compute +
-  // hand-over only, results are garbage), 0 = the product
+  // hand-over + stores, results are garbage), 4 = bare consumer loop (no DMAs, no hand-over, NO STORES: a consumer that ignores the
+  // hand-over must never store, its destination rows may not be written yet), 0 = the product
   constexpr int BN = 32 * NT;
   constexpr int W_BYTES = BN * BK * 4;
   constexpr int STAGE = A_BYTES + W_BYTES;
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(768) void pairs_gemm_pc_kernel(const float *__restr
       }
       for (int c = 0; c < steps; ++c, ++q) {
         const unsigned s = q % RING, fill = q / RING;
-        if (__hip_atomic_load(&s_free[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * fill) {
+        if (debug != 4 && __hip_atomic_load(&s_free[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * fill) {
           // about to wait for the consumers: first make every chunk already issued visible to them (they may be waiting for exactly those)
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           for (; signalled < q; ++signalled)
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(768) void pairs_gemm_pc_kernel(const float *__restr
           FTX_PC_WAIT(s_free, s, 4u * fill);
         }
         const unsigned sa = lds0 + s * STAGE;
-        if (debug != 2) {
+        if (debug != 2 && debug != 4) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) dma::glds16(a_src[u] + c * BK, sa + (wave * 32 + u * 8) * 128);
 #pragma unroll
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(768) void pairs_gemm_pc_kernel(const float *__restr
     for (int c = 0; c < steps; ++c) {
       const unsigned q = (unsigned)j * steps + c;
       const unsigned s = q % RING, fill = q / RING;
-      FTX_PC_WAIT(s_full, s, 4u * (fill + 1));
+      if (debug != 4) FTX_PC_WAIT(s_full, s, 4u * (fill + 1));   // debug 4: bare consumer loop (no hand-over, no stores, garbage operands)
       const char *sa = smem + s * STAGE;
       const char *sw = sa + A_BYTES;
       const char *ap = sa + cw * 32 * 128;
@@ -308,8 +309,10 @@ __global__ __launch_bounds__(768) void pairs_gemm_pc_kernel(const float *__restr
           load_frag((t + 1) & 1, t + 1);
         } else {
           // the last fragments of this slot are in registers once lgkmcnt drains: hand the slot back before the last MFMAs
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (lane == 0) __hip_atomic_fetch_add(&s_free[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (debug != 4) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(&s_free[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
         }
         if (debug != 1) {
 #pragma unroll
@@ -326,10 +329,10 @@ __global__ __launch_bounds__(768) void pairs_gemm_pc_kernel(const float *__restr
 
     // the tile's first chunk was published after its descriptor was written: it is visible now
     const int n0 = s_desc[ts][3];
-    const int d = s_drow[ts][cw * 32 + l31];
+    const int d = (debug == 4) ? -1 : s_drow[ts][cw * 32 + l31];
     const bool zero = d <= -2;
     const int64_t drow = zero ? (int64_t)(-2 - d) : (int64_t)d;
-    if (drow >= 0) {
+    if (drow >= 0 && debug != 4) {
       float *dst = tmp + drow * co;
 #pragma unroll
       for (int jj = 0; jj < NT; ++jj)
