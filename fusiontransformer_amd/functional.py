@@ -41,6 +41,17 @@ def _ws_bytes(fn_name, *args):
     return v
 
 
+def _carve(like, *nbytes):
+    """Raw device pointers of consecutive 256-byte aligned regions of the stream's scratch buffer: the temporaries of ONE call
+    (pair rows, partial statistics, an intermediate gradient, kernel workspaces) that never leave it."""
+    offs, total = [], 0
+    for n in nbytes:
+        offs.append(total)
+        total += (int(n) + 255) & ~255
+    base = _scratch(max(total, 256), like).data_ptr()
+    return [base + o for o in offs]
+
+
 def _scratch(nbytes, like):
     dev = like.device
     if torch.cuda.is_current_stream_capturing():
@@ -630,7 +641,9 @@ class _ConvBNTrain(torch.autograd.Function):
     """spnn.Conv3d -> spnn.BatchNorm (training statistics) (-> + residual) (-> ReLU) as ONE autograd node
     (models/spvcnn.py:22-35,38-50,53-79).  The reduce pass of the convolution produces the BatchNorm's batch statistics while
     it writes the convolution output (ftx_spconv_reduce_stats), so that output is read once, by the apply pass, instead of twice;
-    one node instead of two also halves the host work per layer."""
+    one node instead of two also halves the host work per layer, and everything that does not outlive the call -- the pair rows `tmp`,
+    the partial statistics, the BatchNorm input gradient between the two halves of the backward, the kernel workspaces -- lives in the
+    stream's scratch buffer instead of six allocator round trips per layer and direction."""
 
     @staticmethod
     def forward(ctx, feats, kernel, km, transposed, residual, gamma, beta, running_mean, running_var, momentum, eps, relu):
@@ -646,42 +659,81 @@ class _ConvBNTrain(torch.autograd.Function):
             req(t, F32, "bn " + nm, 1)
             if t.shape[0] != co:
                 raise ValueError("conv_bn: BatchNorm parameter length != output channels")
-        mean, invstd = _empty((co,), F32, feats), _empty((co,), F32, feats)
+        stats = _empty((2, co), F32, feats)              # row 0: batch mean, row 1: 1 / sqrt(var + eps)
+        p_mean, p_invstd = stats.data_ptr(), stats.data_ptr() + 4 * co
+        st = stream()
         direct = (transposed and km.fine_bijective) or n_out == 0 or km.n_pairs == 0
         if direct:
             x = _conv_forward(feats, kernel, km, transposed)
             y = torch.empty_like(x)
             ws_bytes = _ws_bytes("ftx_bn_workspace_bytes", n_out, co)
-            ws = _scratch(ws_bytes, x)
+            ws, = _carve(x, ws_bytes)
             _log_launch("bn_fwd", dict(n=n_out, c=co, reads=2 + (residual is not None), writes=1), lambda: check(L.ftx_bn_train_fwd(
                 ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps),
-                n_out, co, int(relu), ptr(y), ptr(mean), ptr(invstd), ptr(ws), ws_bytes, stream()), "ftx_bn_train_fwd"))
+                n_out, co, int(relu), ptr(y), p_mean, p_invstd, ws, ws_bytes, st), "ftx_bn_train_fwd"))
         else:
             gather, pos = (km.pair_out, km.pos_t) if transposed else (km.pair_in, km.pos)
-            tmp = _empty((km.n_pairs, co), F32, feats)
             x = _empty((n_out, co), F32, feats)
             y = torch.empty_like(x)
-            nb = int(L.ftx_spconv_reduce_stats_blocks(n_out, co))
-            part = torch.empty((nb, 2, co), dtype=torch.float64, device=feats.device)
+            nb = _ws_bytes("ftx_spconv_reduce_stats_blocks", n_out, co)
+            tmp, part = _carve(feats, 4 * km.n_pairs * co, 16 * nb * co)
             meta = dict(pairs=km.n_pairs, n_out=n_out, ca=ca, co=co, kvol=kvol)
             _log_launch("spconv_pairs_gemm", meta, lambda: check(L.ftx_spconv_pairs_gemm(
-                ptr(feats), n_in, ptr(gather), ptr(kernel), 0, ptr(km.koff), km.n_pairs, ca, co, kvol, ptr(tmp), stream()), "ftx_spconv_pairs_gemm"))
+                ptr(feats), n_in, ptr(gather), ptr(kernel), 0, ptr(km.koff), km.n_pairs, ca, co, kvol, tmp, st), "ftx_spconv_pairs_gemm"))
             _log_launch("spconv_reduce", meta, lambda: check(L.ftx_spconv_reduce_stats(
-                ptr(tmp), ptr(pos), n_out, co, kvol, ptr(x), ptr(part), nb, stream()), "ftx_spconv_reduce_stats"))
+                tmp, ptr(pos), n_out, co, kvol, ptr(x), part, nb, st), "ftx_spconv_reduce_stats"))
             _log_launch("bn_fwd", dict(n=n_out, c=co, reads=1 + (residual is not None), writes=1), lambda: check(L.ftx_bn_train_fwd_partials(
                 ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum),
-                float(eps), n_out, co, int(relu), ptr(y), ptr(mean), ptr(invstd), ptr(part), nb, stream()), "ftx_bn_train_fwd_partials"))
-        ctx.save_for_backward(feats, kernel, x, y, gamma, mean, invstd)
+                float(eps), n_out, co, int(relu), ptr(y), p_mean, p_invstd, part, nb, st), "ftx_bn_train_fwd_partials"))
+        ctx.save_for_backward(feats, kernel, x, y, gamma, stats)
         ctx.km, ctx.transposed, ctx.relu, ctx.has_res = km, transposed, int(relu), residual is not None
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        feats, kernel, x, y, gamma, mean, invstd = ctx.saved_tensors
+        L = _lib.load()
+        feats, kernel, x, y, gamma, stats = ctx.saved_tensors
+        km, transposed = ctx.km, ctx.transposed
         gy = req(gy.contiguous(), F32, "conv_bn grad", 2)
-        gx, gres, ggamma, gbeta = _bn_backward_launch(gy, x, y, gamma, mean, invstd, ctx.relu, ctx.has_res)
-        g_feats, g_kernel = _conv_backward(feats, kernel, ctx.km, ctx.transposed, gx, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        return g_feats, g_kernel, None, None, gres, ggamma, gbeta, None, None, None, None, None
+        n, co = x.shape
+        kvol, ca, _ = kernel.shape
+        need_feats, need_kernel = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        st = stream()
+        p_mean, p_invstd = stats.data_ptr(), stats.data_ptr() + 4 * co
+        gparams = _empty((2, co), F32, x)               # row 0: d gamma, row 1: d beta
+        gres = torch.empty_like(x) if ctx.has_res else None
+        bn_ws_bytes = _ws_bytes("ftx_bn_workspace_bytes", n, co)
+        in_side, out_side = (km.pair_out, km.pair_in) if transposed else (km.pair_in, km.pair_out)
+        direct = need_feats and (not transposed) and km.fine_bijective
+        n_feats = feats.shape[0]
+        wg_bytes = _ws_bytes("ftx_spconv_pairs_wgrad_workspace_bytes", km.n_pairs, ca, co, kvol) if (need_kernel and km.n_pairs > 0) else 0
+        tmp_bytes = 4 * km.n_pairs * ca if (need_feats and not direct) else 0
+        bn_ws, gx, tmp, wg_ws = _carve(x, bn_ws_bytes, 4 * n * co, tmp_bytes, wg_bytes)
+        # BatchNorm half: gx = d loss / d (convolution output) stays in the scratch buffer, it is consumed by the two calls below
+        _log_launch("bn_bwd", dict(n=n, c=co, reads=2 * (2 + (1 if ctx.relu else 0)), writes=1 + (1 if ctx.has_res else 0)), lambda: check(L.ftx_bn_train_bwd(
+            ptr(gy), ptr(x), ptr(y), ptr(gamma), p_mean, p_invstd, n, co, ctx.relu, gx, ptr(gres), gparams.data_ptr(), gparams.data_ptr() + 4 * co,
+            bn_ws, bn_ws_bytes, st), "ftx_bn_train_bwd"))
+        g_feats = g_kernel = None
+        meta = dict(pairs=km.n_pairs, n_out=n_feats, ca=co, co=ca, kvol=kvol)
+        if need_feats:
+            g_feats = _empty((n_feats, ca), F32, x)
+            if km.n_pairs == 0 or n_feats == 0:
+                g_feats.zero_()
+            elif direct:
+                _log_launch("spconv_pairs_gemm", dict(meta, direct=True), lambda: check(L.ftx_spconv_pairs_gemm_scatter(
+                    gx, n, ptr(km.pair_out), ptr(km.pair_in), ptr(kernel), 1, ptr(km.koff), km.n_pairs, co, ca, kvol, ptr(g_feats), n_feats, st),
+                    "ftx_spconv_pairs_gemm_scatter"))
+            else:
+                pos_in = km.pos if transposed else km.pos_t
+                _log_launch("spconv_pairs_gemm", meta, lambda: check(L.ftx_spconv_pairs_gemm(
+                    gx, n, ptr(out_side), ptr(kernel), 1, ptr(km.koff), km.n_pairs, co, ca, kvol, tmp, st), "ftx_spconv_pairs_gemm"))
+                _log_launch("spconv_reduce", meta, lambda: check(L.ftx_spconv_reduce(tmp, ptr(pos_in), n_feats, ca, kvol, ptr(g_feats), st), "ftx_spconv_reduce"))
+        if need_kernel:
+            g_kernel = _empty((kvol, ca, co), F32, x)
+            _log_launch("spconv_pairs_wgrad", dict(pairs=km.n_pairs, n_out=n, ca=ca, co=co, kvol=kvol), lambda: check(L.ftx_spconv_pairs_wgrad(
+                ptr(feats), n_feats, ptr(in_side), gx, n, ptr(out_side), ptr(km.koff), km.n_pairs, ca, co, kvol, ptr(g_kernel), wg_ws, wg_bytes, st),
+                "ftx_spconv_pairs_wgrad"))
+        return g_feats, g_kernel, None, None, gres, gparams[0], gparams[1], None, None, None, None, None
 
 
 def conv_bn_train(feats, kernel, km, transposed, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, residual=None, relu=False):
