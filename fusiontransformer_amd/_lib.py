@@ -64,7 +64,7 @@ SIGNATURES = {
     "ftx_spconv_reduce": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "ftx_spconv_reduce_stats_blocks": (_i32, [_i64, _i32]),
     "ftx_spconv_reduce_stats": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp]),
-    "ftx_bn_train_fwd_partials": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "ftx_bn_train_fwd_totals": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ftx_spconv_pairs_wgrad_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "ftx_spconv_pairs_wgrad": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "ftx_bn_workspace_bytes": (_sz, [_i64, _i32]),
@@ -73,6 +73,7 @@ SIGNATURES = {
     "ftx_attn_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     "ftx_attn_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "ftx_attn_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
+    "ftx_attn_set_config": (C.c_int, [_i32, _i32]),
     "ftx_fusion_loss_workspace_bytes": (_sz, []),
     "ftx_fusion_loss": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ftx_fusion_loss_mix": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

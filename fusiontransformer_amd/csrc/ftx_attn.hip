@@ -77,30 +77,34 @@ __device__ inline void mfma_ldsT_x_acc(const float *lds_tile, int col_off, int l
   }
 }
 
-// Stage a 32-row x 64-float tile (rows t0.. of tensor `which`) into LDS with stride TS; rows >= T are zero.
-__device__ inline void tile_prefetch(const float *qkv, int b, int hd, int which, int t0, int T, int nh, int tid, float4 (&r)[2]) {
+// Stage a 32-row x 64-float tile (rows t0.. of tensor `which`) into LDS with stride TS; rows >= T are zero.  NT = threads of the
+// staging group (one key / query group of a block), tid in [0, NT).
+template <int NT>
+__device__ inline void tile_prefetch(const float *qkv, int b, int hd, int which, int t0, int T, int nh, int tid, float4 (&r)[512 / NT]) {
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    int e = q * 256 + tid;
+  for (int q = 0; q < 512 / NT; ++q) {
+    int e = q * NT + tid;
     int row = e >> 4, c4 = (e & 15) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (t0 + row < T) v = *(const float4 *)(qkv_row(qkv, b, t0 + row, which, hd, T, nh) + c4);
     r[q] = v;
   }
 }
-__device__ inline void tile_store(float *lds_tile, int tid, const float4 (&r)[2]) {
+template <int NT>
+__device__ inline void tile_store(float *lds_tile, int tid, const float4 (&r)[512 / NT]) {
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    int e = q * 256 + tid;
+  for (int q = 0; q < 512 / NT; ++q) {
+    int e = q * NT + tid;
     int row = e >> 4, c4 = (e & 15) * 4;
     *(float4 *)&lds_tile[row * TS + c4] = r[q];
   }
 }
 // Same for a (b, t, nh*64) tensor (out / grad_out): head slice of 64 floats per token.
-__device__ inline void tile_prefetch_o(const float *o, int b, int hd, int t0, int T, int nh, int tid, float4 (&r)[2]) {
+template <int NT>
+__device__ inline void tile_prefetch_o(const float *o, int b, int hd, int t0, int T, int nh, int tid, float4 (&r)[512 / NT]) {
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    int e = q * 256 + tid;
+  for (int q = 0; q < 512 / NT; ++q) {
+    int e = q * NT + tid;
     int row = e >> 4, c4 = (e & 15) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (t0 + row < T) v = *(const float4 *)(o + (((int64_t)b * T + t0 + row) * nh + hd) * HD + c4);
@@ -109,24 +113,63 @@ __device__ inline void tile_prefetch_o(const float *o, int b, int hd, int t0, in
 }
 
 // ---------------------------------------------------------------------------------------
-// All three kernels: block = 128 queries (or keys) x SPLIT groups of 4 waves.  Group g walks the inner
-// tiles g, g+SPLIT, ... with its own LDS tile pair and the groups' partial results are merged through
-// LDS at the end.  578 tokens give only 912 (32-row) wave-tiles per layer for 1024 SIMDs; SPLIT = 2
-// puts two waves on every SIMD so one computes while the other waits on LDS / global loads.
+// All three kernels: block = QW waves of 32 queries (or keys) x SPLIT groups.  Group g walks the inner tiles g, g+SPLIT, ... with
+// its own LDS tile pair; the groups' partial results are merged pairwise through LDS at the end (a fixed tree: 0<-1, 2<-3, ..., 0<-2,
+// ..., so the result depends on (QW, SPLIT) only, never on timing).  578 tokens give 19 wave-tiles per (frame, head): 228 per layer at
+// batch 1, 912 at batch 4, for 1024 SIMDs -- so the launcher picks (QW, SPLIT) from the number of wave-tiles: few of them => one wave
+// per group and up to 8 key groups (the serial key loop, which is what bounds a small launch, gets 4x shorter), many => 4 waves
+// sharing each staged tile.  With QW = 1 a group is one wave, which orders its own LDS traffic: no block barrier in the loop.
 // ---------------------------------------------------------------------------------------
-constexpr int ATT_SPLIT = 2;
+template <int QW>
+__device__ inline void group_sync() {
+  if (QW == 1) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+}
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+// floats of LDS: SPLIT tile pairs (+ per-tile row statistics), reused after the loop for SPLIT/2 merge slots of QW x NREG x 64 floats
+template <int QW, int SPLIT, int NREG, int EXTRA>
+constexpr int smem_floats() { return cmax(SPLIT * (2 * 32 * TS + EXTRA), cmax(SPLIT / 2, 1) * QW * NREG * 64); }
+
+// Sum the groups' accumulator tiles into group 0: tree over the groups, fixed order.
+template <int QW, int SPLIT, int NTILES>
+__device__ inline void merge_sum(float *smem, int grp, int wave, int lane, f32x16 (&acc)[NTILES]) {
+  if (SPLIT == 1) return;
+#pragma unroll
+  for (int s = 1; s < SPLIT; s <<= 1) {
+    float *cw = smem + ((grp / (2 * s)) * QW + wave) * (16 * NTILES) * 64 + lane;
+    __syncthreads();   // tiles (round 1) / the slot's previous contents are dead
+    if ((grp & (2 * s - 1)) == s) {
+#pragma unroll
+      for (int t = 0; t < NTILES; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) cw[(t * 16 + g) * 64] = acc[t][g];
+    }
+    __syncthreads();
+    if ((grp & (2 * s - 1)) == 0 && grp + s < SPLIT) {
+#pragma unroll
+      for (int t = 0; t < NTILES; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[t][g] += cw[(t * 16 + g) * 64];
+    }
+  }
+}
 
 // forward: wave = 32 queries; loop over 32-key tiles
-template <int SPLIT>
-__global__ __launch_bounds__(256 * SPLIT) void attn_fwd_kernel(const float *__restrict__ qkv, int T, int nh, float scale,
-                                                               float *__restrict__ out, float *__restrict__ lse) {
-  __shared__ __attribute__((aligned(16))) float Ks[SPLIT][32 * TS];
-  __shared__ __attribute__((aligned(16))) float Vs[SPLIT][32 * TS];
-  __shared__ float comb[SPLIT > 1 ? 4 * 34 * 64 : 1];
-  const int tid = threadIdx.x & 255, grp = threadIdx.x >> 8;
+template <int QW, int SPLIT>
+__global__ __launch_bounds__(64 * QW * SPLIT) void attn_fwd_kernel(const float *__restrict__ qkv, int T, int nh, float scale,
+                                                                   float *__restrict__ out, float *__restrict__ lse) {
+  constexpr int NT = 64 * QW;
+  __shared__ __attribute__((aligned(16))) float smem[smem_floats<QW, SPLIT, 34, 0>()];
+  const int tid = threadIdx.x % NT, grp = threadIdx.x / NT;
+  float *Ks = smem + grp * (2 * 32 * TS), *Vs = Ks + 32 * TS;
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int hd = blockIdx.y, b = blockIdx.z;
-  const int q = blockIdx.x * 128 + wave * 32 + l31;   // this lane's query (the accumulator column)
+  const int q = blockIdx.x * (32 * QW) + wave * 32 + l31;   // this lane's query (the accumulator column)
   const bool qv = q < T;
   const float sl2 = scale * LOG2E;
 
@@ -140,24 +183,24 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_fwd_kernel(const float *__re
 
   const int ntiles = (T + 31) / 32;
   const int iters = (ntiles + SPLIT - 1) / SPLIT;
-  float4 rk[2], rv[2];
-  tile_prefetch(qkv, b, hd, 1, grp * 32, T, nh, tid, rk);
-  tile_prefetch(qkv, b, hd, 2, grp * 32, T, nh, tid, rv);
+  float4 rk[512 / NT], rv[512 / NT];
+  tile_prefetch<NT>(qkv, b, hd, 1, grp * 32, T, nh, tid, rk);
+  tile_prefetch<NT>(qkv, b, hd, 2, grp * 32, T, nh, tid, rv);
   for (int it = 0; it < iters; ++it) {
     const int kt = it * SPLIT + grp;
-    tile_store(Ks[grp], tid, rk);
-    tile_store(Vs[grp], tid, rv);
-    __syncthreads();
+    tile_store<NT>(Ks, tid, rk);
+    tile_store<NT>(Vs, tid, rv);
+    group_sync<QW>();
     if (it + 1 < iters) {
-      tile_prefetch(qkv, b, hd, 1, (kt + SPLIT) * 32, T, nh, tid, rk);
-      tile_prefetch(qkv, b, hd, 2, (kt + SPLIT) * 32, T, nh, tid, rv);
+      tile_prefetch<NT>(qkv, b, hd, 1, (kt + SPLIT) * 32, T, nh, tid, rk);
+      tile_prefetch<NT>(qkv, b, hd, 2, (kt + SPLIT) * 32, T, nh, tid, rv);
     }
     if (kt < ntiles) {
       // S^T[key][q]: rows = keys of this tile, column = this lane's query
       f32x16 st;
 #pragma unroll
       for (int g = 0; g < 16; ++g) st[g] = 0.f;
-      mfma_lds_x_frag(Ks[grp], l31, h, qf, st);
+      mfma_lds_x_frag(Ks, l31, h, qf, st);
       float mx = -INFINITY;
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
@@ -185,15 +228,17 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_fwd_kernel(const float *__re
         o1[g] *= alpha;
       }
       // O^T[dv][q] += sum_key V[key][dv] * P^T[key][q]
-      mfma_ldsT_x_acc(Vs[grp], 0, l31, h, st, o0);
-      mfma_ldsT_x_acc(Vs[grp], 32, l31, h, st, o1);
+      mfma_ldsT_x_acc(Vs, 0, l31, h, st, o0);
+      mfma_ldsT_x_acc(Vs, 32, l31, h, st, o1);
     }
-    __syncthreads();
+    group_sync<QW>();
   }
-  if (SPLIT > 1) {   // merge the groups' (m, l, O) in group order
-    for (int r = 1; r < SPLIT; ++r) {
-      float *cw = comb + wave * 34 * 64 + lane;
-      if (grp == r) {
+  if (SPLIT > 1) {   // merge the groups' (m, l, O): tree in fixed order
+#pragma unroll
+    for (int s = 1; s < SPLIT; s <<= 1) {
+      float *cw = smem + ((grp / (2 * s)) * QW + wave) * 34 * 64 + lane;
+      __syncthreads();
+      if ((grp & (2 * s - 1)) == s) {
         cw[0] = m;
         cw[64] = l;
 #pragma unroll
@@ -203,10 +248,10 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_fwd_kernel(const float *__re
         }
       }
       __syncthreads();
-      if (grp == 0) {
+      if ((grp & (2 * s - 1)) == 0 && grp + s < SPLIT) {
         const float m1 = cw[0], l1 = cw[64];
         const float mt = fmaxf(m, m1);
-        const float a0 = exp2f(m - mt), a1 = (m1 == -INFINITY) ? 0.f : exp2f(m1 - mt);
+        const float a0 = (m == -INFINITY) ? 0.f : exp2f(m - mt), a1 = (m1 == -INFINITY) ? 0.f : exp2f(m1 - mt);
         l = l * a0 + l1 * a1;
         m = mt;
 #pragma unroll
@@ -215,7 +260,6 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_fwd_kernel(const float *__re
           o1[g] = o1[g] * a0 + cw[(18 + g) * 64] * a1;
         }
       }
-      __syncthreads();
     }
   }
   if (qv && grp == 0) {
@@ -254,42 +298,18 @@ __global__ void attn_delta_kernel(const float *__restrict__ o, const float *__re
   }
 }
 
-// Sum the groups' accumulator tiles (NREG registers per lane) into group 0, in group order.
-template <int SPLIT, int NTILES>
-__device__ inline void merge_sum(float *comb, int grp, int wave, int lane, f32x16 (&acc)[NTILES]) {
-  if (SPLIT == 1) return;
-  for (int r = 1; r < SPLIT; ++r) {
-    float *cw = comb + wave * (16 * NTILES) * 64 + lane;
-    if (grp == r) {
-#pragma unroll
-      for (int t = 0; t < NTILES; ++t)
-#pragma unroll
-        for (int g = 0; g < 16; ++g) cw[(t * 16 + g) * 64] = acc[t][g];
-    }
-    __syncthreads();
-    if (grp == 0) {
-#pragma unroll
-      for (int t = 0; t < NTILES; ++t)
-#pragma unroll
-        for (int g = 0; g < 16; ++g) acc[t][g] += cw[(t * 16 + g) * 64];
-    }
-    __syncthreads();
-  }
-}
-
 // dK, dV: wave = 32 keys; loop over 32-query tiles
-template <int SPLIT>
-__global__ __launch_bounds__(256 * SPLIT) void attn_bwd_kv_kernel(const float *__restrict__ qkv, const float *__restrict__ go,
-                                                                  const float *__restrict__ lse, const float *__restrict__ delta, int T,
-                                                                  int nh, float scale, float *__restrict__ gqkv) {
-  __shared__ __attribute__((aligned(16))) float Qs[SPLIT][32 * TS];
-  __shared__ __attribute__((aligned(16))) float Gs[SPLIT][32 * TS];
-  __shared__ float s_lse[SPLIT][32], s_delta[SPLIT][32];
-  __shared__ float comb[SPLIT > 1 ? 4 * 64 * 64 : 1];
-  const int tid = threadIdx.x & 255, grp = threadIdx.x >> 8;
+template <int QW, int SPLIT>
+__global__ __launch_bounds__(64 * QW * SPLIT) void attn_bwd_kv_kernel(const float *__restrict__ qkv, const float *__restrict__ go,
+                                                                      const float *__restrict__ lse, const float *__restrict__ delta, int T,
+                                                                      int nh, float scale, float *__restrict__ gqkv) {
+  constexpr int NT = 64 * QW;
+  __shared__ __attribute__((aligned(16))) float smem[smem_floats<QW, SPLIT, 64, 64>()];
+  const int tid = threadIdx.x % NT, grp = threadIdx.x / NT;
+  float *Qs = smem + grp * (2 * 32 * TS + 64), *Gs = Qs + 32 * TS, *s_lse = Gs + 32 * TS, *s_delta = s_lse + 32;
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int hd = blockIdx.y, b = blockIdx.z;
-  const int key = blockIdx.x * 128 + wave * 32 + l31;   // accumulator column = this lane's key
+  const int key = blockIdx.x * (32 * QW) + wave * 32 + l31;   // accumulator column = this lane's key
   const bool kv = key < T;
   const float sl2 = scale * LOG2E;
 
@@ -305,47 +325,47 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_bwd_kv_kernel(const float *_
 
   const int ntiles = (T + 31) / 32;
   const int iters = (ntiles + SPLIT - 1) / SPLIT;
-  float4 rq[2], rg[2];
-  tile_prefetch(qkv, b, hd, 0, grp * 32, T, nh, tid, rq);
-  tile_prefetch_o(go, b, hd, grp * 32, T, nh, tid, rg);
+  float4 rq[512 / NT], rg[512 / NT];
+  tile_prefetch<NT>(qkv, b, hd, 0, grp * 32, T, nh, tid, rq);
+  tile_prefetch_o<NT>(go, b, hd, grp * 32, T, nh, tid, rg);
   for (int it = 0; it < iters; ++it) {
     const int qt = it * SPLIT + grp;
-    tile_store(Qs[grp], tid, rq);
-    tile_store(Gs[grp], tid, rg);
+    tile_store<NT>(Qs, tid, rq);
+    tile_store<NT>(Gs, tid, rg);
     if (tid < 32) {
       int t = qt * 32 + tid;
-      s_lse[grp][tid] = t < T ? lse[((int64_t)b * nh + hd) * T + t] * LOG2E : 0.f;
-      s_delta[grp][tid] = t < T ? delta[((int64_t)b * nh + hd) * T + t] : 0.f;
+      s_lse[tid] = t < T ? lse[((int64_t)b * nh + hd) * T + t] * LOG2E : 0.f;
+      s_delta[tid] = t < T ? delta[((int64_t)b * nh + hd) * T + t] : 0.f;
     }
-    __syncthreads();
+    group_sync<QW>();
     if (it + 1 < iters) {
-      tile_prefetch(qkv, b, hd, 0, (qt + SPLIT) * 32, T, nh, tid, rq);
-      tile_prefetch_o(go, b, hd, (qt + SPLIT) * 32, T, nh, tid, rg);
+      tile_prefetch<NT>(qkv, b, hd, 0, (qt + SPLIT) * 32, T, nh, tid, rq);
+      tile_prefetch_o<NT>(go, b, hd, (qt + SPLIT) * 32, T, nh, tid, rg);
     }
     if (qt < ntiles) {
       // S[q][key] and dP[q][key]: rows = queries of the tile, column = this lane's key
       f32x16 s, dp;
 #pragma unroll
       for (int g = 0; g < 16; ++g) s[g] = dp[g] = 0.f;
-      mfma_lds_x_frag(Qs[grp], l31, h, kf, s);
-      mfma_lds_x_frag(Gs[grp], l31, h, vf, dp);
+      mfma_lds_x_frag(Qs, l31, h, kf, s);
+      mfma_lds_x_frag(Gs, l31, h, vf, dp);
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         int r = acc_row(g, h);
         bool ok = kv && (qt * 32 + r < T);
-        float p = ok ? exp2f(s[g] * sl2 - s_lse[grp][r]) : 0.f;
+        float p = ok ? exp2f(s[g] * sl2 - s_lse[r]) : 0.f;
         s[g] = p;                                            // P
-        dp[g] = p * (dp[g] - s_delta[grp][r]) * scale;        // dS
+        dp[g] = p * (dp[g] - s_delta[r]) * scale;             // dS
       }
       // dV^T[dv][key] += sum_q dO[q][dv] P[q][key];  dK^T[d][key] += sum_q Q[q][d] dS[q][key]
-      mfma_ldsT_x_acc(Gs[grp], 0, l31, h, s, acc[0]);
-      mfma_ldsT_x_acc(Gs[grp], 32, l31, h, s, acc[1]);
-      mfma_ldsT_x_acc(Qs[grp], 0, l31, h, dp, acc[2]);
-      mfma_ldsT_x_acc(Qs[grp], 32, l31, h, dp, acc[3]);
+      mfma_ldsT_x_acc(Gs, 0, l31, h, s, acc[0]);
+      mfma_ldsT_x_acc(Gs, 32, l31, h, s, acc[1]);
+      mfma_ldsT_x_acc(Qs, 0, l31, h, dp, acc[2]);
+      mfma_ldsT_x_acc(Qs, 32, l31, h, dp, acc[3]);
     }
-    __syncthreads();
+    group_sync<QW>();
   }
-  merge_sum<SPLIT, 4>(comb, grp, wave, lane, acc);
+  merge_sum<QW, SPLIT, 4>(smem, grp, wave, lane, acc);
   if (kv && grp == 0) {
     float *kp = gqkv + ((((int64_t)b * T + key) * 3 + 1) * nh + hd) * HD;
     float *vp = gqkv + ((((int64_t)b * T + key) * 3 + 2) * nh + hd) * HD;
@@ -361,17 +381,17 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_bwd_kv_kernel(const float *_
 }
 
 // dQ: wave = 32 queries; loop over 32-key tiles
-template <int SPLIT>
-__global__ __launch_bounds__(256 * SPLIT) void attn_bwd_q_kernel(const float *__restrict__ qkv, const float *__restrict__ go,
-                                                                 const float *__restrict__ lse, const float *__restrict__ delta, int T,
-                                                                 int nh, float scale, float *__restrict__ gqkv) {
-  __shared__ __attribute__((aligned(16))) float Ks[SPLIT][32 * TS];
-  __shared__ __attribute__((aligned(16))) float Vs[SPLIT][32 * TS];
-  __shared__ float comb[SPLIT > 1 ? 4 * 32 * 64 : 1];
-  const int tid = threadIdx.x & 255, grp = threadIdx.x >> 8;
+template <int QW, int SPLIT>
+__global__ __launch_bounds__(64 * QW * SPLIT) void attn_bwd_q_kernel(const float *__restrict__ qkv, const float *__restrict__ go,
+                                                                     const float *__restrict__ lse, const float *__restrict__ delta, int T,
+                                                                     int nh, float scale, float *__restrict__ gqkv) {
+  constexpr int NT = 64 * QW;
+  __shared__ __attribute__((aligned(16))) float smem[smem_floats<QW, SPLIT, 32, 0>()];
+  const int tid = threadIdx.x % NT, grp = threadIdx.x / NT;
+  float *Ks = smem + grp * (2 * 32 * TS), *Vs = Ks + 32 * TS;
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int hd = blockIdx.y, b = blockIdx.z;
-  const int q = blockIdx.x * 128 + wave * 32 + l31;
+  const int q = blockIdx.x * (32 * QW) + wave * 32 + l31;
   const bool qv = q < T;
   const float sl2 = scale * LOG2E;
 
@@ -387,25 +407,25 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_bwd_q_kernel(const float *__
 
   const int ntiles = (T + 31) / 32;
   const int iters = (ntiles + SPLIT - 1) / SPLIT;
-  float4 rk[2], rv[2];
-  tile_prefetch(qkv, b, hd, 1, grp * 32, T, nh, tid, rk);
-  tile_prefetch(qkv, b, hd, 2, grp * 32, T, nh, tid, rv);
+  float4 rk[512 / NT], rv[512 / NT];
+  tile_prefetch<NT>(qkv, b, hd, 1, grp * 32, T, nh, tid, rk);
+  tile_prefetch<NT>(qkv, b, hd, 2, grp * 32, T, nh, tid, rv);
   for (int it = 0; it < iters; ++it) {
     const int kt = it * SPLIT + grp;
-    tile_store(Ks[grp], tid, rk);
-    tile_store(Vs[grp], tid, rv);
-    __syncthreads();
+    tile_store<NT>(Ks, tid, rk);
+    tile_store<NT>(Vs, tid, rv);
+    group_sync<QW>();
     if (it + 1 < iters) {
-      tile_prefetch(qkv, b, hd, 1, (kt + SPLIT) * 32, T, nh, tid, rk);
-      tile_prefetch(qkv, b, hd, 2, (kt + SPLIT) * 32, T, nh, tid, rv);
+      tile_prefetch<NT>(qkv, b, hd, 1, (kt + SPLIT) * 32, T, nh, tid, rk);
+      tile_prefetch<NT>(qkv, b, hd, 2, (kt + SPLIT) * 32, T, nh, tid, rv);
     }
     if (kt < ntiles) {
       // S^T[key][q], dP^T[key][q]
       f32x16 st, dpt;
 #pragma unroll
       for (int g = 0; g < 16; ++g) st[g] = dpt[g] = 0.f;
-      mfma_lds_x_frag(Ks[grp], l31, h, qf, st);
-      mfma_lds_x_frag(Vs[grp], l31, h, gf, dpt);
+      mfma_lds_x_frag(Ks, l31, h, qf, st);
+      mfma_lds_x_frag(Vs, l31, h, gf, dpt);
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         bool ok = qv && (kt * 32 + acc_row(g, h) < T);
@@ -413,12 +433,12 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_bwd_q_kernel(const float *__
         dpt[g] = p * (dpt[g] - my_delta) * scale;   // dS^T
       }
       // dQ^T[d][q] += sum_key K[key][d] dS^T[key][q]
-      mfma_ldsT_x_acc(Ks[grp], 0, l31, h, dpt, acc[0]);
-      mfma_ldsT_x_acc(Ks[grp], 32, l31, h, dpt, acc[1]);
+      mfma_ldsT_x_acc(Ks, 0, l31, h, dpt, acc[0]);
+      mfma_ldsT_x_acc(Ks, 32, l31, h, dpt, acc[1]);
     }
-    __syncthreads();
+    group_sync<QW>();
   }
-  merge_sum<SPLIT, 2>(comb, grp, wave, lane, acc);
+  merge_sum<QW, SPLIT, 2>(smem, grp, wave, lane, acc);
   if (qv && grp == 0) {
     float *qp = gqkv + ((((int64_t)b * T + q) * 3 + 0) * nh + hd) * HD;
 #pragma unroll
@@ -437,12 +457,50 @@ static int attn_check(const char *who, int b, int t, int h, int d) {
   return FTX_OK;
 }
 
+// (QW, SPLIT) of a launch.  0 = pick from the number of 32-row wave-tiles (see the comment above attn_fwd_kernel).
+static int g_attn_qw = 0, g_attn_split = 0;
+extern "C" int ftx_attn_set_config(int32_t qw, int32_t split) {
+  const bool ok = (qw == 0 && split == 0) || (qw == 4 && split == 2) || (qw == 2 && (split == 2 || split == 4)) ||
+                  (qw == 1 && (split == 2 || split == 4 || split == 8));
+  FTX_REQUIRE(ok, "ftx_attn_set_config: (%d, %d) is not a built configuration", qw, split);
+  g_attn_qw = qw;
+  g_attn_split = split;
+  return FTX_OK;
+}
+// Measured at 578 tokens x 12 heads (tools/bench_attn.py, us fwd / bwd): batch 1 (228 wave-tiles) (4,2) 52 / 170, (1,8) 21 / 75,
+// (1,4) 23 / 70; batch 2 (4,2) 52 / 170, (2,4) 34 / 103; batch 4 (4,2) 54 / 174, (2,4) 65 / 199; batch 8 (4,2) 106 / 342, others slower.
+static void attn_config(int b, int t, int h, bool backward, int &qw, int &split) {
+  if (g_attn_qw) {
+    qw = g_attn_qw;
+    split = g_attn_split;
+    return;
+  }
+  const int64_t wave_tiles = (int64_t)ceil_div(t, 32) * h * b;
+  const int64_t simds = 4 * (int64_t)device_cus();
+  if (wave_tiles * 4 <= simds) { qw = 1; split = backward ? 4 : 8; }   // a quarter of the SIMDs or fewer: shortest key loop
+  else if (wave_tiles * 2 <= simds) { qw = 2; split = 4; }
+  else { qw = 4; split = 2; }
+}
+
+#define ATTN_DISPATCH(KERNEL, ...)                                                                               \
+  do {                                                                                                           \
+    dim3 grid((unsigned)ceil_div(t, 32 * qw), (unsigned)h, (unsigned)b);                                         \
+    if (qw == 4) KERNEL<4, 2><<<grid, 512, 0, st>>>(__VA_ARGS__);                                                \
+    else if (qw == 2 && split == 2) KERNEL<2, 2><<<grid, 256, 0, st>>>(__VA_ARGS__);                             \
+    else if (qw == 2) KERNEL<2, 4><<<grid, 512, 0, st>>>(__VA_ARGS__);                                           \
+    else if (split == 2) KERNEL<1, 2><<<grid, 128, 0, st>>>(__VA_ARGS__);                                        \
+    else if (split == 4) KERNEL<1, 4><<<grid, 256, 0, st>>>(__VA_ARGS__);                                        \
+    else KERNEL<1, 8><<<grid, 512, 0, st>>>(__VA_ARGS__);                                                        \
+  } while (0)
+
 extern "C" int ftx_attn_fwd(const float *qkv, int32_t b, int32_t t, int32_t h, int32_t d, float scale, float *out, float *lse, void *stream) {
   int rc = attn_check("ftx_attn_fwd", b, t, h, d);
   if (rc != FTX_OK) return rc;
   FTX_REQUIRE(qkv && out && lse, "ftx_attn_fwd: null pointer");
-  dim3 grid((unsigned)ceil_div(t, 128), (unsigned)h, (unsigned)b);
-  attn_fwd_kernel<ATT_SPLIT><<<grid, 256 * ATT_SPLIT, 0, (hipStream_t)stream>>>(qkv, t, h, scale, out, lse);
+  hipStream_t st = (hipStream_t)stream;
+  int qw, split;
+  attn_config(b, t, h, false, qw, split);
+  ATTN_DISPATCH(attn_fwd_kernel, qkv, t, h, scale, out, lse);
   return check_launch("ftx_attn_fwd");
 }
 
@@ -464,8 +522,9 @@ extern "C" int ftx_attn_bwd(const float *qkv, const float *out, const float *gra
   float *delta = (float *)workspace;
   const int64_t rows = (int64_t)b * t * h;
   attn_delta_kernel<<<(unsigned)ceil_div(rows * 16, 256), 256, 0, st>>>(out, grad_out, rows, t, h, delta);
-  dim3 grid((unsigned)ceil_div(t, 128), (unsigned)h, (unsigned)b);
-  attn_bwd_kv_kernel<ATT_SPLIT><<<grid, 256 * ATT_SPLIT, 0, st>>>(qkv, grad_out, lse, delta, t, h, scale, grad_qkv);
-  attn_bwd_q_kernel<ATT_SPLIT><<<grid, 256 * ATT_SPLIT, 0, st>>>(qkv, grad_out, lse, delta, t, h, scale, grad_qkv);
+  int qw, split;
+  attn_config(b, t, h, true, qw, split);
+  ATTN_DISPATCH(attn_bwd_kv_kernel, qkv, grad_out, lse, delta, t, h, scale, grad_qkv);
+  ATTN_DISPATCH(attn_bwd_q_kernel, qkv, grad_out, lse, delta, t, h, scale, grad_qkv);
   return check_launch("ftx_attn_bwd");
 }

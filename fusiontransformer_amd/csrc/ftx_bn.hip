@@ -4,9 +4,35 @@
 // forward (statistics, apply) and the output written once; statistics accumulate in
 // float64 so mean/var do not depend on how rows are split over workgroups.
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include "ftx_common.h"
+#include "ftx_lastblock.h"
 
 using namespace ftx;
+
+namespace ftx {
+StreamScratch stream_scratch(hipStream_t st) {
+  static std::mutex mu;
+  static std::map<hipStream_t, StreamScratch> pool;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = pool.find(st);
+  if (it != pool.end()) return it->second;
+  StreamScratch sc{nullptr, nullptr};
+  const size_t cbytes = 512 * ((sizeof(uint32_t) * (1 + LB_MAX_GROUPS) + 511) / 512);
+  const size_t gbytes = sizeof(double) * (size_t)LB_MAX_GROUPS * 2 * LB_MAX_COLS;
+  char *base = nullptr;
+  if (hipMalloc((void **)&base, cbytes + gbytes) != hipSuccess || hipMemsetAsync(base, 0, cbytes, st) != hipSuccess) {
+    set_error("stream_scratch: cannot allocate the per-stream ticket buffer (%s)", hipGetErrorString(hipGetLastError()));
+    if (base) (void)hipFree(base);
+    return sc;
+  }
+  sc.counters = (uint32_t *)base;
+  sc.gpart = (double *)(base + cbytes);
+  pool[st] = sc;
+  return sc;
+}
+}  // namespace ftx
 
 // Grid of the statistics passes.  They stream 1-3 row matrices once and are bound by loads in flight, not by bytes: at 128 rows per
 // block the 81k-row level ran 635 blocks (2.5 per CU) and reached 1.7 TB/s; FTX_BN_ROWS / FTX_BN_MAX_BLOCKS keep the knobs measurable.
@@ -15,7 +41,7 @@ static int bn_blocks(int64_t n) {
   static const int maxb = getenv("FTX_BN_MAX_BLOCKS") ? atoi(getenv("FTX_BN_MAX_BLOCKS")) : 2048;
   int64_t b = ceil_div(n, rows > 0 ? rows : 48);
   if (b > maxb) b = maxb;
-  if (b > 4096) b = 4096;
+  if (b > LB_GROUP * LB_MAX_GROUPS) b = LB_GROUP * LB_MAX_GROUPS;
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -46,7 +72,8 @@ template <class Op>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                          const float *__restrict__ y, const float *__restrict__ mean,
                                                          const float *__restrict__ invstd, int relu, int64_t n, int c,
-                                                         double *__restrict__ part) {
+                                                         double *part, StreamScratch sc) {
+  // part: gridDim.x rows [2][c], then the totals row [2][c] written by the last block to finish (ftx_lastblock.h)
   extern __shared__ double sh[];  // [2][RL][c]
   const int c4 = c >> 2;
   const int RL = 256 / c4 > 0 ? 256 / c4 : 1;
@@ -94,56 +121,51 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict
     int which = j / c, col = j - which * c;
     double s = 0;
     for (int q = 0; q < RL; ++q) s += sh[(which * RL + q) * c + col];
-    part[((int64_t)blockIdx.x * 2 + which) * c + col] = s;
+    lb_store(&part[((int64_t)blockIdx.x * 2 + which) * c + col], s);
   }
+  __syncthreads();   // sh is free again: 2 * RL * c = 2048 doubles >= 256 + 2c for c <= 512
+  last_block_totals(part, (int)gridDim.x, c, sc, sh, StoreTotals{part + (int64_t)gridDim.x * 2 * c, c});
 }
 
-// One wave per channel: lanes stride over the per-block partials, then a shuffle tree.
-__device__ inline double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
-
-__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const double *__restrict__ part, int nb, int64_t n, int c, float eps,
-                                                              float momentum, float *__restrict__ running_mean,
-                                                              float *__restrict__ running_var, float *__restrict__ save_mean,
-                                                              float *__restrict__ save_invstd) {
-  const int lane = threadIdx.x & 63;
-  const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (col >= c) return;
-  double s = 0, ss = 0;
-  for (int b = lane; b < nb; b += 64) {
-    s += part[((int64_t)b * 2 + 0) * c + col];
-    ss += part[((int64_t)b * 2 + 1) * c + col];
-  }
-  s = wave_sum(s);
-  ss = wave_sum(ss);
-  if (lane == 0) {
-    double mean = s / (double)n;
-    double var = ss / (double)n - mean * mean;
-    if (var < 0) var = 0;
-    save_mean[col] = (float)mean;
-    save_invstd[col] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) running_mean[col] = (1.f - momentum) * running_mean[col] + momentum * (float)mean;
-    if (running_var) {
-      double unbiased = n > 1 ? var * (double)n / (double)(n - 1) : var;
-      running_var[col] = (1.f - momentum) * running_var[col] + momentum * (float)unbiased;
-    }
-  }
+// mean / invstd of a column from its two totals, in float64 (every apply block computes the same values; block 0 also stores them
+// and updates the running statistics -- the work of the former finalize launch).
+__device__ inline void bn_column_stats(double s, double ss, int64_t n, float eps, float &mean, float &invstd, double &var_out) {
+  const double m = s / (double)n;
+  double var = ss / (double)n - m * m;
+  if (var < 0) var = 0;
+  mean = (float)m;
+  invstd = (float)(1.0 / sqrt(var + (double)eps));
+  var_out = var;
 }
 
 // Apply passes: thread (column group cg, row lane rl) keeps its four channels' constants in registers and walks rows rl, rl + RL*grid, ...
 // two at a time (independent 16-byte loads in flight); RL = 256 / (c/4) rows per block and trip.
 __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float *__restrict__ x, const float *__restrict__ res, const float *__restrict__ gamma,
-                                                           const float *__restrict__ beta, const float *__restrict__ mean,
-                                                           const float *__restrict__ invstd, int64_t n, int c, int relu, float *__restrict__ y) {
+                                                           const float *__restrict__ beta, const double *__restrict__ totals, float eps,
+                                                           float momentum, float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                           float *__restrict__ save_mean, float *__restrict__ save_invstd, int64_t n, int c,
+                                                           int relu, float *__restrict__ y) {
   const int c4 = c >> 2;
   const int RL = 256 / c4 > 0 ? 256 / c4 : 1;
   const int cg = threadIdx.x % c4, rl = threadIdx.x / c4;
   if (rl >= RL) return;
   const int col = cg * 4;
-  const float4 mu = *(const float4 *)&mean[col], is = *(const float4 *)&invstd[col];
+  float mu_[4], is_[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    double var;
+    bn_column_stats(totals[col + v], totals[c + col + v], n, eps, mu_[v], is_[v], var);
+    if (blockIdx.x == 0 && rl == 0) {
+      save_mean[col + v] = mu_[v];
+      save_invstd[col + v] = is_[v];
+      if (running_mean) running_mean[col + v] = (1.f - momentum) * running_mean[col + v] + momentum * mu_[v];
+      if (running_var) {
+        const double unbiased = n > 1 ? var * (double)n / (double)(n - 1) : var;
+        running_var[col + v] = (1.f - momentum) * running_var[col + v] + momentum * (float)unbiased;
+      }
+    }
+  }
+  const float4 mu = make_float4(mu_[0], mu_[1], mu_[2], mu_[3]), is = make_float4(is_[0], is_[1], is_[2], is_[3]);
   const float4 g = *(const float4 *)&gamma[col], b = *(const float4 *)&beta[col];
   auto one = [&](int64_t r) {
     const int64_t o = r * c + col;
@@ -205,27 +227,28 @@ extern "C" int ftx_bn_train_fwd(const float *x, const float *residual, const flo
     return FTX_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
+  const StreamScratch sc = stream_scratch(st);
+  if (!sc.counters) return FTX_ELAUNCH;
   const int nb = bn_blocks(n);
   double *part = (double *)workspace;
-  bn_partial_kernel<FwdOp><<<nb, 256, bn_partial_lds(c), st>>>(x, nullptr, nullptr, nullptr, nullptr, 0, n, c, part);
-  bn_finalize_fwd_kernel<<<ceil_div(c, 4), 256, 0, st>>>(part, nb, n, c, eps, momentum, running_mean, running_var, save_mean, save_invstd);
-  bn_apply_fwd_kernel<<<bn_apply_grid(n, c), 256, 0, st>>>(x, residual, gamma, beta, save_mean, save_invstd, n, c, relu, y);
+  bn_partial_kernel<FwdOp><<<nb, 256, bn_partial_lds(c), st>>>(x, nullptr, nullptr, nullptr, nullptr, 0, n, c, part, sc);
+  bn_apply_fwd_kernel<<<bn_apply_grid(n, c), 256, 0, st>>>(x, residual, gamma, beta, part + (size_t)nb * 2 * c, eps, momentum, running_mean,
+                                                           running_var, save_mean, save_invstd, n, c, relu, y);
   return check_launch("ftx_bn_train_fwd");
 }
 
-// BatchNorm forward whose statistics were produced by the pass that wrote x (ftx_spconv_reduce_stats): `part` holds nb
-// per-block partial (sum, sum of squares) rows, float64.  Finalize + apply only: x is read once instead of twice.
-extern "C" int ftx_bn_train_fwd_partials(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean,
-                                         float *running_var, float momentum, float eps, int64_t n, int32_t c, int32_t relu, float *y,
-                                         float *save_mean, float *save_invstd, const double *part, int32_t nb, void *stream) {
-  int rc = bn_check("ftx_bn_train_fwd_partials", n, c);
+// BatchNorm forward whose statistics were produced by the pass that wrote x (ftx_spconv_reduce_stats): `totals` is the row
+// [2][c] of float64 column sums / sums of squares that pass leaves behind its partial rows.  One launch: x is read once.
+extern "C" int ftx_bn_train_fwd_totals(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean,
+                                       float *running_var, float momentum, float eps, int64_t n, int32_t c, int32_t relu, float *y,
+                                       float *save_mean, float *save_invstd, const double *totals, void *stream) {
+  int rc = bn_check("ftx_bn_train_fwd_totals", n, c);
   if (rc != FTX_OK) return rc;
-  FTX_REQUIRE(n >= 1 && nb >= 1, "ftx_bn_train_fwd_partials: needs at least one row and one partial");
-  FTX_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && part, "ftx_bn_train_fwd_partials: null pointer");
-  hipStream_t st = (hipStream_t)stream;
-  bn_finalize_fwd_kernel<<<ceil_div(c, 4), 256, 0, st>>>(part, nb, n, c, eps, momentum, running_mean, running_var, save_mean, save_invstd);
-  bn_apply_fwd_kernel<<<bn_apply_grid(n, c), 256, 0, st>>>(x, residual, gamma, beta, save_mean, save_invstd, n, c, relu, y);
-  return check_launch("ftx_bn_train_fwd_partials");
+  FTX_REQUIRE(n >= 1, "ftx_bn_train_fwd_totals: needs at least one row");
+  FTX_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && totals, "ftx_bn_train_fwd_totals: null pointer");
+  bn_apply_fwd_kernel<<<bn_apply_grid(n, c), 256, 0, (hipStream_t)stream>>>(x, residual, gamma, beta, totals, eps, momentum, running_mean,
+                                                                            running_var, save_mean, save_invstd, n, c, relu, y);
+  return check_launch("ftx_bn_train_fwd_totals");
 }
 
 __global__ void bn_apply_eval_kernel(const float *__restrict__ x, const float *__restrict__ res, const float *__restrict__ gamma,
@@ -263,30 +286,11 @@ extern "C" int ftx_bn_eval_fwd(const float *x, const float *residual, const floa
   return check_launch("ftx_bn_eval_fwd");
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const double *__restrict__ part, int nb, int c, double *__restrict__ sums,
-                                                              float *__restrict__ grad_gamma, float *__restrict__ grad_beta) {
-  const int lane = threadIdx.x & 63;
-  const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (col >= c) return;
-  double s = 0, ss = 0;
-  for (int b = lane; b < nb; b += 64) {
-    s += part[((int64_t)b * 2 + 0) * c + col];
-    ss += part[((int64_t)b * 2 + 1) * c + col];
-  }
-  s = wave_sum(s);
-  ss = wave_sum(ss);
-  if (lane == 0) {
-    sums[col] = s;
-    sums[c + col] = ss;
-    if (grad_beta) grad_beta[col] = (float)s;
-    if (grad_gamma) grad_gamma[col] = (float)ss;
-  }
-}
-
 __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restrict__ gy, const float *__restrict__ x, const float *__restrict__ y,
                                                            const float *__restrict__ gamma, const float *__restrict__ mean,
                                                            const float *__restrict__ invstd, const double *__restrict__ sums, int64_t n, int c,
-                                                           int relu, float *__restrict__ gx, float *__restrict__ gres) {
+                                                           int relu, float *__restrict__ gx, float *__restrict__ gres,
+                                                           float *__restrict__ grad_gamma, float *__restrict__ grad_beta) {
   const int c4 = c >> 2;
   const int RL = 256 / c4 > 0 ? 256 / c4 : 1;
   const int cg = threadIdx.x % c4, rl = threadIdx.x / c4;
@@ -301,6 +305,10 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restri
     gm[v] = gamma[col + v];
     sdy[v] = (float)sums[col + v] * inv_n;
     sdyx[v] = (float)sums[c + col + v] * inv_n;
+    if (blockIdx.x == 0 && rl == 0) {   // the parameter gradients are the two totals themselves
+      if (grad_beta) grad_beta[col + v] = (float)sums[col + v];
+      if (grad_gamma) grad_gamma[col + v] = (float)sums[c + col + v];
+    }
   }
   auto one = [&](int64_t r) {
     const int64_t o = r * c + col;
@@ -347,11 +355,13 @@ extern "C" int ftx_bn_train_bwd(const float *grad_y, const float *x, const float
     return FTX_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
+  const StreamScratch sc = stream_scratch(st);
+  if (!sc.counters) return FTX_ELAUNCH;
   const int nb = bn_blocks(n);
   double *part = (double *)workspace;
-  double *sums = part + (size_t)nb * 2 * c;
-  bn_partial_kernel<BwdOp><<<nb, 256, bn_partial_lds(c), st>>>(x, grad_y, relu ? y : nullptr, save_mean, save_invstd, relu, n, c, part);
-  bn_finalize_bwd_kernel<<<ceil_div(c, 4), 256, 0, st>>>(part, nb, c, sums, grad_gamma, grad_beta);
-  bn_apply_bwd_kernel<<<bn_apply_grid(n, c), 256, 0, st>>>(grad_y, x, y, gamma, save_mean, save_invstd, sums, n, c, relu, grad_x, grad_residual);
+  double *sums = part + (size_t)nb * 2 * c;   // written by the last block of the statistics pass
+  bn_partial_kernel<BwdOp><<<nb, 256, bn_partial_lds(c), st>>>(x, grad_y, relu ? y : nullptr, save_mean, save_invstd, relu, n, c, part, sc);
+  bn_apply_bwd_kernel<<<bn_apply_grid(n, c), 256, 0, st>>>(grad_y, x, y, gamma, save_mean, save_invstd, sums, n, c, relu, grad_x, grad_residual,
+                                                           grad_gamma, grad_beta);
   return check_launch("ftx_bn_train_bwd");
 }

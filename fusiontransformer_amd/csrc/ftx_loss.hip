@@ -82,6 +82,11 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const float *__restrict_
                                                         float *__restrict__ g3b, float *__restrict__ g2b, long long *__restrict__ conf3,
                                                         long long *__restrict__ conf2, double *__restrict__ part) {
   __shared__ double sh[4];
+  // confusion counts of this block, flushed once at the end: the points of a frame fall on a few dominant (label, prediction) cells,
+  // and one global 64-bit atomic per point on those cells serialised the kernel (100 us for 22 k points)
+  __shared__ unsigned int cf3[LC_MAX * LC_MAX], cf2[LC_MAX * LC_MAX];
+  for (int j = threadIdx.x; j < c * c; j += blockDim.x) cf3[j] = cf2[j] = 0u;
+  __syncthreads();
   const bool dual = (l3b != l3);
   const float invW = ce_scale * (float)(1.0 / wsum[0]);   // d(ce_scale * CE) / d(logits) carries the mix factor
   const float invN = 1.f / (float)n;
@@ -100,8 +105,8 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const float *__restrict_
       a_ce3 += (double)(-w * lp3.v[y]);
       a_ce2 += (double)(-w * lp2.v[y]);
       if (y != ignore_index) {
-        if (conf3) atomicAdd((unsigned long long *)&conf3[y * c + am3], 1ull);
-        if (conf2) atomicAdd((unsigned long long *)&conf2[y * c + am2], 1ull);
+        if (conf3) atomicAdd(&cf3[y * c + am3], 1u);
+        if (conf2) atomicAdd(&cf2[y * c + am2], 1u);
       }
     }
     // cross-entropy gradients (weighted mean): w/W * (softmax - onehot)
@@ -168,6 +173,11 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const float *__restrict_
   if (threadIdx.x == 0) {
     double *p = part + (int64_t)blockIdx.x * 4;
     p[0] = r0; p[1] = r1; p[2] = r2; p[3] = r3;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < c * c; j += blockDim.x) {   // integer counts: the order of the adds does not matter
+    if (conf3 && cf3[j]) atomicAdd((unsigned long long *)&conf3[j], (unsigned long long)cf3[j]);
+    if (conf2 && cf2[j]) atomicAdd((unsigned long long *)&conf2[j], (unsigned long long)cf2[j]);
   }
 }
 

@@ -360,6 +360,7 @@ static void launch_pairs_gemm(int nt, dim3 grid, hipStream_t st, const float *A,
   }
 }
 
+#include "ftx_lastblock.h"
 #include "ftx_spconv_dma.h"
 #include "ftx_spconv_split.h"
 #include "ftx_spconv_pc.h"
@@ -561,10 +562,10 @@ extern "C" int ftx_spconv_reduce(const float *tmp, const int32_t *pos, int64_t n
 // per-block partials: the BatchNorm that follows every convolution (models/spvcnn.py:22-35,53-79) then needs no pass of its own
 // over `out`.  Block = (256 / (co/4)) rows x co/4 float4 columns over a contiguous row range; a thread keeps one column, so its
 // eight float64 sums stay in registers; rows of a block are summed in a fixed order and blocks are combined in block order by
-// ftx_bn_train_fwd_partials: the statistics do not depend on the launch geometry beyond `nb`, and are bit-reproducible.
+// ftx_lastblock.h (then one apply launch, ftx_bn_train_fwd_totals): the statistics do not depend on the launch geometry beyond `nb`, and are bit-reproducible.
 template <int KVOL>
 __global__ __launch_bounds__(256) void spconv_reduce_stats_kernel(const float *__restrict__ tmp, const int32_t *__restrict__ pos, int64_t n, int co,
-                                                                  int kvol, float *__restrict__ out, double *__restrict__ part) {
+                                                                  int kvol, float *__restrict__ out, double *part, StreamScratch sc) {
   extern __shared__ double sh[];  // [2][RL][co]
   const int cv = co >> 2;
   const int RL = 256 / cv;
@@ -615,8 +616,11 @@ __global__ __launch_bounds__(256) void spconv_reduce_stats_kernel(const float *_
     int which = e / co, col = e - which * co;
     double s = 0;
     for (int q = 0; q < RL; ++q) s += sh[(which * RL + q) * co + col];
-    part[((int64_t)blockIdx.x * 2 + which) * co + col] = s;
+    lb_store(&part[((int64_t)blockIdx.x * 2 + which) * co + col], s);
   }
+  // column totals [2][co] behind the nb partial rows, by the last block to finish (ftx_lastblock.h): what ftx_bn_train_fwd_totals reads
+  __syncthreads();   // sh is free again: 2 * RL * co = 2048 doubles >= 256 + 2 co for co <= 512
+  last_block_totals(part, (int)gridDim.x, co, sc, sh, StoreTotals{part + (int64_t)gridDim.x * 2 * co, co});
 }
 
 extern "C" int32_t ftx_spconv_reduce_stats_blocks(int64_t n, int32_t co) {
@@ -629,18 +633,20 @@ extern "C" int32_t ftx_spconv_reduce_stats_blocks(int64_t n, int32_t co) {
 
 extern "C" int ftx_spconv_reduce_stats(const float *tmp, const int32_t *pos, int64_t n, int32_t co, int32_t kvol, float *out, double *part,
                                        int32_t nb, void *stream) {
-  FTX_REQUIRE(n >= 1 && kvol >= 1 && co >= 4 && co % 4 == 0 && co <= 1024, "ftx_spconv_reduce_stats: bad size");
+  FTX_REQUIRE(n >= 1 && kvol >= 1 && co >= 4 && co % 4 == 0 && co <= 512, "ftx_spconv_reduce_stats: bad size (co must be a multiple of 4 in [4, 512])");
   FTX_REQUIRE(pos && out && part, "ftx_spconv_reduce_stats: null pointer");
   FTX_REQUIRE(nb == ftx_spconv_reduce_stats_blocks(n, co), "ftx_spconv_reduce_stats: nb must come from ftx_spconv_reduce_stats_blocks");
   hipStream_t st = (hipStream_t)stream;
+  const StreamScratch sc = stream_scratch(st);
+  if (!sc.counters) return FTX_ELAUNCH;
   const int rl = 256 / (co / 4);
   const size_t lds = sizeof(double) * 2 * rl * co;
   if (kvol == 27)
-    spconv_reduce_stats_kernel<27><<<nb, 256, lds, st>>>(tmp, pos, n, co, kvol, out, part);
+    spconv_reduce_stats_kernel<27><<<nb, 256, lds, st>>>(tmp, pos, n, co, kvol, out, part, sc);
   else if (kvol == 8)
-    spconv_reduce_stats_kernel<8><<<nb, 256, lds, st>>>(tmp, pos, n, co, kvol, out, part);
+    spconv_reduce_stats_kernel<8><<<nb, 256, lds, st>>>(tmp, pos, n, co, kvol, out, part, sc);
   else
-    spconv_reduce_stats_kernel<0><<<nb, 256, lds, st>>>(tmp, pos, n, co, kvol, out, part);
+    spconv_reduce_stats_kernel<0><<<nb, 256, lds, st>>>(tmp, pos, n, co, kvol, out, part, sc);
   return check_launch("ftx_spconv_reduce_stats");
 }
 
@@ -1002,18 +1008,6 @@ static int wgrad_occ(const WgradCfg &c) {
   if (c.mi == 3) return wgrad_occ_n<3, 1>(c);
   if (c.wmg == 1) return wgrad_occ_n<2, 1>(c);
   return wgrad_occ_n<2, 2>(c);
-}
-static int device_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) {
-      (void)hipGetLastError();
-      n = 256;
-    }
-    cus = n;
-  }
-  return cus;
 }
 
 // Pairs per tile.  All blocks of a launch should be resident together: a launch of 1.2x the resident slots takes as long as one of 2x

@@ -640,7 +640,8 @@ def _bn_backward_launch(gy, x, y, gamma, mean, invstd, relu, has_res):
 class _ConvBNTrain(torch.autograd.Function):
     """spnn.Conv3d -> spnn.BatchNorm (training statistics) (-> + residual) (-> ReLU) as ONE autograd node
     (models/spvcnn.py:22-35,38-50,53-79).  The reduce pass of the convolution produces the BatchNorm's batch statistics while
-    it writes the convolution output (ftx_spconv_reduce_stats), so that output is read once, by the apply pass, instead of twice;
+    it writes the convolution output (ftx_spconv_reduce_stats: the last block to finish leaves the column totals), so that output is read
+    once, by the one apply launch (ftx_bn_train_fwd_totals), instead of twice;
     one node instead of two also halves the host work per layer, and everything that does not outlive the call -- the pair rows `tmp`,
     the partial statistics, the BatchNorm input gradient between the two halves of the backward, the kernel workspaces -- lives in the
     stream's scratch buffer instead of six allocator round trips per layer and direction."""
@@ -676,15 +677,15 @@ class _ConvBNTrain(torch.autograd.Function):
             x = _empty((n_out, co), F32, feats)
             y = torch.empty_like(x)
             nb = _ws_bytes("ftx_spconv_reduce_stats_blocks", n_out, co)
-            tmp, part = _carve(feats, 4 * km.n_pairs * co, 16 * nb * co)
+            tmp, part = _carve(feats, 4 * km.n_pairs * co, 16 * (nb + 1) * co)    # nb partial rows + the totals row, float64
             meta = dict(pairs=km.n_pairs, n_out=n_out, ca=ca, co=co, kvol=kvol)
             _log_launch("spconv_pairs_gemm", meta, lambda: check(L.ftx_spconv_pairs_gemm(
                 ptr(feats), n_in, ptr(gather), ptr(kernel), 0, ptr(km.koff), km.n_pairs, ca, co, kvol, tmp, st), "ftx_spconv_pairs_gemm"))
             _log_launch("spconv_reduce", meta, lambda: check(L.ftx_spconv_reduce_stats(
                 tmp, ptr(pos), n_out, co, kvol, ptr(x), part, nb, st), "ftx_spconv_reduce_stats"))
-            _log_launch("bn_fwd", dict(n=n_out, c=co, reads=1 + (residual is not None), writes=1), lambda: check(L.ftx_bn_train_fwd_partials(
+            _log_launch("bn_fwd", dict(n=n_out, c=co, reads=1 + (residual is not None), writes=1), lambda: check(L.ftx_bn_train_fwd_totals(
                 ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum),
-                float(eps), n_out, co, int(relu), ptr(y), p_mean, p_invstd, part, nb, st), "ftx_bn_train_fwd_partials"))
+                float(eps), n_out, co, int(relu), ptr(y), p_mean, p_invstd, part + 16 * nb * co, st), "ftx_bn_train_fwd_totals"))
         ctx.save_for_backward(feats, kernel, x, y, gamma, stats)
         ctx.km, ctx.transposed, ctx.relu, ctx.has_res = km, transposed, int(relu), residual is not None
         return y

@@ -198,9 +198,11 @@ int ftx_rows_gemm(const float *A, int64_t n, const float *W, int32_t w_transpose
 /* out[r,:] = sum over k (ascending) of tmp[pos[k,r],:] for pos >= 0; out (n, co) fully written. */
 int ftx_spconv_reduce(const float *tmp, const int32_t *pos, int64_t n, int32_t co, int32_t kvol, float *out, void *stream);
 
-/* The reduce pass that also produces the BatchNorm statistics of its output: part (nb, 2, co) float64 per-block partial
- * (sum, sum of squares), nb = ftx_spconv_reduce_stats_blocks(n, co).  Feed `part` to ftx_bn_train_fwd_partials: the
- * Conv3d -> BatchNorm pair of every SPVCNN block (models/spvcnn.py:22-35,53-79) then reads the convolution output once. */
+/* The reduce pass that also produces the BatchNorm statistics of its output: part (nb + 1, 2, co) float64 -- nb per-block
+ * partial (sum, sum of squares) rows, nb = ftx_spconv_reduce_stats_blocks(n, co), then ONE row of column totals, summed in block
+ * order by whichever block finishes last (no second launch; bit-reproducible).  Feed `part + nb*2*co` to
+ * ftx_bn_train_fwd_totals: the Conv3d -> BatchNorm pair of every SPVCNN block (models/spvcnn.py:22-35,53-79) then reads the
+ * convolution output once.  Uses a small per-stream ticket buffer owned by the library (allocated at first use on a stream). */
 int32_t ftx_spconv_reduce_stats_blocks(int64_t n, int32_t co);
 int ftx_spconv_reduce_stats(const float *tmp, const int32_t *pos, int64_t n, int32_t co, int32_t kvol, float *out, double *part, int32_t nb, void *stream);
 
@@ -219,8 +221,9 @@ int ftx_spconv_pairs_wgrad(const float *A, int64_t rows_a, const int32_t *idx_a,
  * running_mean / running_var may be NULL (no update).  residual may be NULL. */
 size_t ftx_bn_workspace_bytes(int64_t n, int32_t c);
 int ftx_bn_train_fwd(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean, float *running_var, float momentum, float eps, int64_t n, int32_t c, int32_t relu, float *y, float *save_mean, float *save_invstd, void *workspace, size_t workspace_bytes, void *stream);
-/* Training-mode BatchNorm forward from per-block partial statistics produced by ftx_spconv_reduce_stats (finalize + apply). */
-int ftx_bn_train_fwd_partials(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean, float *running_var, float momentum, float eps, int64_t n, int32_t c, int32_t relu, float *y, float *save_mean, float *save_invstd, const double *part, int32_t nb, void *stream);
+/* Training-mode BatchNorm forward from the column totals (2, c) float64 that ftx_spconv_reduce_stats left: one launch that
+ * derives mean / invstd, updates the running statistics, stores save_mean / save_invstd and applies. */
+int ftx_bn_train_fwd_totals(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean, float *running_var, float momentum, float eps, int64_t n, int32_t c, int32_t relu, float *y, float *save_mean, float *save_invstd, const double *totals, void *stream);
 
 /* Eval forward with running statistics. */
 int ftx_bn_eval_fwd(const float *x, const float *residual, const float *gamma, const float *beta, const float *running_mean, const float *running_var, float eps, int64_t n, int32_t c, int32_t relu, float *y, void *stream);
@@ -237,6 +240,10 @@ int ftx_attn_fwd(const float *qkv, int32_t b, int32_t t, int32_t h, int32_t d, f
 /* grad_qkv (b, t, 3, h, d) fully written.  workspace: ftx_attn_bwd_workspace_bytes(b, t, h). */
 size_t ftx_attn_bwd_workspace_bytes(int32_t b, int32_t t, int32_t h);
 int ftx_attn_bwd(const float *qkv, const float *out, const float *grad_out, const float *lse, int32_t b, int32_t t, int32_t h, int32_t d, float scale, float *grad_qkv, void *workspace, size_t workspace_bytes, void *stream);
+/* Tiling of the three attention kernels: qw waves of 32 queries (keys) per block x split key (query) groups.  (0, 0) = chosen per launch
+ * from b*h*ceil(t/32) against the device's SIMD count (default); built: (4,2) (2,2) (2,4) (1,2) (1,4) (1,8).  A measurement / test aid:
+ * results of different tilings differ in the last bits (the key range is summed in a different grouping), never with timing. */
+int ftx_attn_set_config(int32_t qw, int32_t split);
 
 /* ---- fused train-step losses + metric: modules/SemanticTrainer.py:158-194, models/metric.py:37-58 ----
  * losses[0] = loss_2d = CE_w(img_logit) + lambda * KL(softmax(lidar_logit) || softmax(img_logit2))

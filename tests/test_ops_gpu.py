@@ -204,7 +204,7 @@ def test_sparse_conv_fwd_bwd(env, ca, co, ks, cur, s):
                                                                  (4, 32, 3, 1, 1, False, False, False), (384, 256, 3, 2, 1, False, True, True)])
 def test_fused_conv_batchnorm_node_matches_oracle_ops(env, ca, co, ks, cur, s, transposed, res, relu):
     """Conv3d -> BatchNorm(train) (+residual) (+ReLU) as one node whose reduce pass produces the batch statistics
-    (ftx_spconv_reduce_stats / ftx_bn_train_fwd_partials), against the oracle's conv followed by torch's batch_norm on the CPU:
+    (ftx_spconv_reduce_stats / ftx_bn_train_fwd_totals), against the oracle's conv followed by torch's batch_norm on the CPU:
     output, running statistics and every gradient."""
     spf, O = env
     from fusiontransformer_amd.sparse import CoordinateManager
@@ -456,6 +456,32 @@ def test_attention_matches_timm_formula(env, B, T, H):
     out.backward(dev(go))
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(x.grad.cpu().numpy(), r.grad.numpy(), rtol=1e-3, atol=2e-5)
+
+
+@pytest.mark.parametrize("cfg", [(4, 2), (2, 2), (2, 4), (1, 2), (1, 4), (1, 8)])
+def test_attention_every_tiling(env, cfg):
+    """Each built (waves per block, key groups) tiling of the three attention kernels against the fp64 formula, on a shape with ragged
+    tails (70 = 2 full tiles + 6 rows, so some key groups of the wide splits get no tile at all) and on the ViT's 578 tokens."""
+    spf, O = env
+    L = spf._lib.load()
+    rng = np.random.default_rng(13)
+    try:
+        assert L.ftx_attn_set_config(*cfg) == 0
+        for B, T, H in [(1, 70, 2), (1, 578, 3)]:
+            qkv = rng.standard_normal((B, T, 3, H, 64)).astype(np.float32)
+            go = rng.standard_normal((B, T, H * 64)).astype(np.float32)
+            r = torch.from_numpy(qkv).double().requires_grad_(True)
+            q, k, v = r.permute(2, 0, 3, 1, 4)
+            ref = (((q @ k.transpose(-2, -1)) * 0.125).softmax(dim=-1) @ v).transpose(1, 2).reshape(B, T, H * 64)
+            ref.backward(torch.from_numpy(go).double())
+            x = dev(qkv).requires_grad_(True)
+            out = spf.attention(x, 0.125)
+            out.backward(dev(go))
+            np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=2e-6)
+            np.testing.assert_allclose(x.grad.cpu().numpy(), r.grad.numpy(), rtol=1e-3, atol=2e-5)
+    finally:
+        L.ftx_attn_set_config(0, 0)
+    assert L.ftx_attn_set_config(3, 2) != 0      # not a built tiling: refused, nothing changes
 
 
 def test_attention_large_logits_are_stable(env):
@@ -726,12 +752,13 @@ def test_round2_entry_points_edge_cases(env):
     pos = torch.full((27, 1), -1, dtype=torch.int32, device="cuda")
     pos[13, 0] = 0
     nb = int(L.ftx_spconv_reduce_stats_blocks(1, 8))
-    part = torch.empty((nb, 2, 8), dtype=torch.float64, device="cuda")
+    part = torch.empty((nb + 1, 2, 8), dtype=torch.float64, device="cuda")      # nb partial rows + the totals row
     o1 = torch.empty(1, 8, device="cuda")
     assert L.ftx_spconv_reduce_stats(tmp.data_ptr(), pos.data_ptr(), 1, 8, 27, o1.data_ptr(), part.data_ptr(), nb, spf.stream()) == 0
     assert torch.equal(o1, tmp)
-    np.testing.assert_allclose(part.sum(0)[0].cpu().numpy(), tmp[0].double().cpu().numpy(), rtol=0, atol=0)
-    np.testing.assert_allclose(part.sum(0)[1].cpu().numpy(), (tmp[0].double() ** 2).cpu().numpy(), rtol=1e-15)
+    np.testing.assert_allclose(part[:nb].sum(0)[0].cpu().numpy(), tmp[0].double().cpu().numpy(), rtol=0, atol=0)
+    np.testing.assert_allclose(part[:nb].sum(0)[1].cpu().numpy(), (tmp[0].double() ** 2).cpu().numpy(), rtol=1e-15)
+    assert torch.equal(part[nb], part[:nb].sum(0))                               # totals by the last block to finish
     assert L.ftx_spconv_reduce_stats(tmp.data_ptr(), pos.data_ptr(), 1, 8, 27, o1.data_ptr(), part.data_ptr(), nb + 1, spf.stream()) != 0
     # the fused loss refuses an unknown mix
     with pytest.raises(ValueError):

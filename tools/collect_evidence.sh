@@ -16,10 +16,12 @@ FTX_DIST_BACKEND=gloo FTX_FORCE_DEVICE=0 python -m torch.distributed.run --nnode
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ev_two -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-batch1 --no-nuscenes > $O/prof_two_bench.json 2>/dev/null
 cp $(find /tmp/ev_two -name "*kernel_stats.csv" | head -1) $O/rocprof_two_stream_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ev_ser -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-batch1 --no-nuscenes --serial-branches > $O/prof_serial_bench.json 2>/dev/null
+# serial issue AND an eagerly executed trunk (FTX_VIT_GRAPHS=0: the same kernels, but no capture warm-up passes that would inflate the ViT
+# kernels' per-step counts): every kernel's count and duration is its own
+FTX_VIT_GRAPHS=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ev_ser -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-batch1 --no-nuscenes --serial-branches > $O/prof_serial_bench.json 2>/dev/null
 cp $(find /tmp/ev_ser -name "*kernel_stats.csv" | head -1) $O/rocprof_serial_stats.csv
-python3 $R/tools/prof_summary.py $O/rocprof_serial_stats.csv 7 > $O/rocprof_serial_summary.txt; head -22 $O/rocprof_serial_summary.txt
-python3 $R/tools/prof_summary.py $O/rocprof_two_stream_stats.csv 7 > $O/rocprof_two_stream_summary.txt
+(echo "# rocprofv3 --kernel-trace --stats of: FTX_VIT_GRAPHS=0 bench.py --steps 5 --warmup 2 --serial-branches (7 steps; one stream, eager trunk)"; python3 $R/tools/prof_summary.py $O/rocprof_serial_stats.csv 7) > $O/rocprof_serial_summary.txt; head -22 $O/rocprof_serial_summary.txt
+(echo "# rocprofv3 --kernel-trace --stats of: bench.py --steps 5 --warmup 2 (two streams, graphed trunk).  The graph capture replays the trunk 4 extra times, so the"; echo "# ViT rows (library GEMM, attention, layernorm, part of elementwise) are 11/7 of their per-step values here; the serial summary has the exact ones."; python3 $R/tools/prof_summary.py $O/rocprof_two_stream_stats.csv 7) > $O/rocprof_two_stream_summary.txt
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/ev_f -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch1 --no-nuscenes > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/ev_w -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch1 --no-nuscenes > /dev/null 2>&1
 python3 $R/tools/pmc_hbm.py $(find /tmp/ev_f -name "*counter_collection.csv" | head -1) $(find /tmp/ev_w -name "*counter_collection.csv" | head -1) 3 > $O/pmc_hbm_spconv.json
