@@ -201,6 +201,9 @@ def main():
     ap.add_argument("--serial-branches", action="store_true",
                     help="issue the image and LiDAR branches back to back on one stream in every step (profiling aid: under rocprofv3 "
                          "each kernel's duration is then its own, as in the roofline block's HIP-event timings)")
+    ap.add_argument("--index-prefetch", action="store_true",
+                    help="build the coordinate structures of batch i+1 during step i (TrainStep(next_batch=...)) instead of inside its own forward; "
+                         "measured slower on MI355X (batch 4: 128.8 against 139.7 frames/s), off by default")
     ap.add_argument("--no-tune-gemm", dest="tune_gemm", action="store_false", help="skip TunableOp selection of the library GEMM kernels")
     args = ap.parse_args()
 
@@ -252,8 +255,11 @@ def main():
 
     if rank == 0:
         log("model and %d resident batches (%s points) resident; warm-up" % (len(datas), points))
+    # --index-prefetch: while step i runs, the coordinate structures of batch i+1 are built on a third stream (TrainStep(next_batch=...)).
+    # Every step then builds exactly one set -- the one the NEXT step consumes -- so the K timed steps contain K index builds either way.
+    nxt = (lambda seq, i: seq[(i + 1) % len(seq)]) if args.index_prefetch else (lambda seq, i: None)
     for i in range(args.warmup):
-        step(datas[i % len(datas)])
+        step(datas[i % len(datas)], nxt(datas, i))
     barrier()
     if rank == 0:
         log("timing %d steps" % args.steps)
@@ -267,7 +273,8 @@ def main():
             # the kernels' own and not inflated by the ViT GEMMs running beside them.
             launch_log = spf.LAUNCH_LOG = []
             model.overlap_branches = False
-        step(datas[i % len(datas)])
+        j = args.warmup + i            # continue the warm-up's alternation: the batch of step j was prepared by step j - 1
+        step(datas[j % len(datas)], nxt(datas, j))
     spf.LAUNCH_LOG = None
     model.overlap_branches = not args.serial_branches
     barrier()
@@ -293,6 +300,8 @@ def main():
                        "frames_per_gpu": args.batch, "global_batch": args.batch * world, "points_per_gpu_batch": n_points,
                        "resident_batches_cycled": len(datas), "points_of_each_resident_batch": points,
                        "attention": args.attn, "library_gemm_tuning": bool(args.tune_gemm), "branch_overlap": "off (--serial-branches)" if args.serial_branches else "2 HIP streams (image / LiDAR)",
+                       "index_prefetch": ("coordinate structures of batch i+1 built during step i on a third stream; one build per timed step" if args.index_prefetch
+                                          else "off: every batch's coordinate structures are built inside its own forward"),
                        "parallelism": "dp%d" % world},
             "frames_per_sec_per_gpu": round(frames / elapsed / world, 3),
             "roofline": roof,
@@ -344,11 +353,11 @@ def main():
             ones = [build_inputs(cfg, 1, args.shape, rank, device, cycle=c)[1] for c in range(max(1, args.cycle))]
             one = ones[0]
             for i in range(4):
-                step(ones[i % len(ones)])
+                step(ones[i % len(ones)], nxt(ones, i))
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for i in range(10):
-                step(ones[i % len(ones)])
+            for i in range(4, 14):
+                step(ones[i % len(ones)], nxt(ones, i))
             torch.cuda.synchronize()
             ms1 = 1e3 * (time.perf_counter() - t1) / 10
             out["config"]["batch1_configs1_literal"] = {"frames_per_sec": round(1e3 / ms1, 2), "ms_per_step": round(ms1, 3), "steps": 10,
@@ -367,12 +376,13 @@ def main():
             step_n = TrainStep(cfg_n, model_n, metrics=(m2n, m3n))
             nbs = [build_inputs(cfg_n, args.batch, "nuscenes", rank, device, cycle=c) for c in range(max(1, args.cycle))]
             nb = nbs[0][0]
+            nds = [d for _, d in nbs]
             for i in range(4):
-                step_n(nbs[i % len(nbs)][1])
+                step_n(nds[i % len(nds)], nxt(nds, i))
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for i in range(10):
-                step_n(nbs[i % len(nbs)][1])
+            for i in range(4, 14):
+                step_n(nds[i % len(nds)], nxt(nds, i))
             torch.cuda.synchronize()
             msn = 1e3 * (time.perf_counter() - t1) / 10
             out["config"]["nuscenes_shaped_configs2"] = {"frames_per_sec": round(args.batch * 1e3 / msn, 2), "ms_per_step": round(msn, 3), "steps": 10,

@@ -82,6 +82,17 @@ def bump_batchnorm_counters(model):
         torch._foreach_add_(live, 1)
 
 
+def prepare_batch(model, data_dict):
+    """Build the coordinate structures of `data_dict` (voxel hash, the five levels' kernel maps, point <-> voxel indices) ahead of
+    the forward that will receive it, on a stream of their own (SPVCNN.prepare).  The forward then finds them on
+    data_dict["lidar"]; a batch that was not prepared builds them inside the forward as before.  Returns data_dict."""
+    lb = getattr(model, "lidar_backbone", None)
+    lidar = data_dict.get("lidar") if isinstance(data_dict, dict) else None
+    if lb is not None and lidar is not None and hasattr(lb, "prepare"):
+        lb.prepare(lidar)
+    return data_dict
+
+
 def _drain(steps):
     while True:
         try:

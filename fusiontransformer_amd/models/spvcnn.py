@@ -16,8 +16,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import functional as spf
-from ..sparse import PointTensor, SparseTensor, cat
-from .utils import initial_voxelize, initial_voxelize_steps, point_to_voxel, voxel_to_point
+from ..sparse import PointTensor, PreparedIndex, SparseTensor, cat, drain, index_stream as _index_stream
+from .utils import initial_voxelize, initial_voxelize_steps, point_index, point_to_voxel, voxel_index, voxel_to_point
 
 __all__ = ["SPVCNN", "Conv3d", "BatchNorm", "ReLU"]
 
@@ -233,18 +233,13 @@ class SPVCNN(nn.Module):
         """The same forward as a generator that yields at stage boundaries, so a scheduler can interleave
         the issue of this branch with the image branch (see _fusion_common.run_fusion).  It yields
         "need_early" / "need_middle" right before it touches the image features."""
-        coords = x.C
-        if coords.dtype != torch.float32:
-            coords = coords.float()
-        z = PointTensor(x.F, coords.contiguous())
-
-        # index structures first: they depend on the coordinates only.  Each data-dependent size is read back after
-        # a "sync" yield (6 per batch), so the scheduler issues image-branch work instead of waiting for it.
-        if os.environ.get("FTX_EAGER_INDEX_READS") == "1":   # A/B aid: block on every read as it comes
-            x0 = initial_voxelize(z, self.pres, self.vres)
+        prepared = getattr(x, "prepared", None)
+        if prepared is not None:
+            # built ahead of this forward on the index stream (prepare()): wait for it, and tell the allocator this stream uses it
+            z, x0 = prepared.take(torch.cuda.current_stream() if x.F.is_cuda else None)
+            x.prepared = None
         else:
-            x0 = yield from initial_voxelize_steps(z, self.pres, self.vres)
-            yield from x0.cm.unet_levels_steps((1, 2, 4, 8, 16))
+            z, x0 = yield from self._index_steps(x)
         yield "voxelized"
         x0 = self._stem(x0)
         z0 = voxel_to_point(x0, z, nearest=False)
@@ -297,6 +292,47 @@ class SPVCNN(nn.Module):
         z3.F = z3.F + _linear_bn_relu(self.point_transforms[2], z2.F)
         self.last_index = dict(x0=x0, x1=x1, x2=x2, x3=x3, x4=x4, z=z)
         return z3.F
+
+    def _index_steps(self, x, ahead=False):
+        """Everything of a batch that depends on its coordinates only: the voxelisation of the points, the voxel hash, the
+        coordinates and kernel maps of the five U-Net levels and (ahead=True) the point <-> voxel index structures of the strides
+        the network visits.  Each data-dependent size is read back after a "sync" yield (6 per batch), so a scheduler can issue
+        image-branch work instead of waiting for it."""
+        coords = x.C
+        if coords.dtype != torch.float32:
+            coords = coords.float()
+        z = PointTensor(x.F, coords.contiguous())
+        if os.environ.get("FTX_EAGER_INDEX_READS") == "1":   # A/B aid: block on every read as it comes
+            x0 = initial_voxelize(z, self.pres, self.vres)
+        else:
+            x0 = yield from initial_voxelize_steps(z, self.pres, self.vres)
+            yield from x0.cm.unet_levels_steps((1, 2, 4, 8, 16))
+        if ahead:
+            cm, seg = x0.cm, torch.is_grad_enabled()
+            # the strides of voxel_to_point / point_to_voxel in _backbone_steps: x0 / y4 (1), x4 (16), y2 (4)
+            point_index(cm, 1, z, cm.coords[1].shape[0], with_segments=seg)
+            for s_ in (16, 4):
+                n = cm.coords[s_].shape[0]
+                point_index(cm, s_, z, n, with_segments=seg)
+                voxel_index(cm, s_, z, n)
+        return z, x0
+
+    def prepare(self, x):
+        """Build the coordinate structures of batch `x` (a SparseTensor as the forward takes it) NOW, on a stream of their own, and
+        hang them on `x`; the forward that later receives `x` starts at the first convolution.  Meant to be called for batch i+1
+        while step i is in flight (trainer.TrainStep(next_batch=...)): the index build is a chain of ~230 small kernels with six
+        host reads, and inside the forward each read waits for everything queued before it -- the previous step's backward."""
+        if getattr(x, "prepared", None) is not None or not x.F.is_cuda:
+            return x
+        with torch.cuda.device(x.F.device):      # the current device is per thread (prepare may run on a helper thread)
+            s_idx = _index_stream(x.F.device)
+            s_idx.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.device(x.F.device), torch.cuda.stream(s_idx), torch.set_grad_enabled(self.training):   # training: also the backward's sorted segments
+            z, x0 = drain(self._index_steps(x, ahead=True))
+            ev = torch.cuda.Event()
+            ev.record()
+        x.prepared = PreparedIndex(z, x0, ev)
+        return x
 
     def forward(self, x):
         return self._backbone(x)

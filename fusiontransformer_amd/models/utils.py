@@ -10,7 +10,7 @@ import torch
 from .. import functional as spf
 from ..sparse import CoordinateManager, HostRead, PointTensor, SparseTensor, drain
 
-__all__ = ["initial_voxelize", "initial_voxelize_steps", "point_to_voxel", "voxel_to_point"]
+__all__ = ["initial_voxelize", "initial_voxelize_steps", "point_to_voxel", "voxel_to_point", "voxel_index", "point_index"]
 
 
 def initial_voxelize(z: PointTensor, init_res, after_res) -> SparseTensor:
@@ -51,19 +51,38 @@ def initial_voxelize_steps(z: PointTensor, init_res, after_res):
     return new_tensor
 
 
+def voxel_index(cm: CoordinateManager, stride: int, z: PointTensor, n_vox: int):
+    """The coordinate-only half of point_to_voxel at `stride` (hash query, counts, sorted segments), cached on `z`."""
+    pc_hash = spf.sphash(spf.floor_coords(z.C, stride))
+    idx_query = cm.table(stride).query(pc_hash)              # sphashquery(pc_hash, sphash(x.C))
+    z.additional_features["idx_query"][stride] = idx_query
+    z.additional_features["counts"][stride] = spf.spcount(idx_query, n_vox)
+    z.additional_features.setdefault("vox_seg", {})[stride] = spf.voxelize_segments(idx_query, n_vox)
+
+
+def point_index(cm: CoordinateManager, stride: int, z: PointTensor, n_vox: int, nearest=False, with_segments=True):
+    """The coordinate-only half of voxel_to_point at `stride` (8 corner rows, trilinear weights and -- for the backward -- the
+    (point, corner) entries sorted by voxel), cached on `z`."""
+    off = cm.offsets(2, stride, z.F.device)                  # KernelRegion(2, x.s, 1)
+    floored = spf.floor_coords(z.C, stride)
+    # sphash(floored, off) + sphashquery against sphash(x.C), fused; (8, N) -> (N, 8)
+    idx_query = spf.kernel_map_build(floored, off, cm.table(stride)).transpose(0, 1).contiguous()
+    weights = spf.calc_ti_weights(z.C, idx_query, scale=stride)
+    if nearest:
+        weights[:, 1:] = 0.0
+        idx_query[:, 1:] = -1
+    z.idx_query[stride] = idx_query
+    z.weights[stride] = weights
+    z.additional_features.setdefault("devox_seg", {})[stride] = spf.devoxelize_segments(idx_query, weights, n_vox) if with_segments else None
+
+
 def point_to_voxel(x: SparseTensor, z: PointTensor) -> SparseTensor:
     """reference models/utils.py:40-63."""
     if z.additional_features is None or z.additional_features.get("idx_query") is None \
             or z.additional_features["idx_query"].get(x.s) is None:
-        pc_hash = spf.sphash(spf.floor_coords(z.C, x.s))
-        idx_query = x.cm.table(x.s).query(pc_hash)           # sphashquery(pc_hash, sphash(x.C))
-        counts = spf.spcount(idx_query, x.C.shape[0])
-        z.additional_features["idx_query"][x.s] = idx_query
-        z.additional_features["counts"][x.s] = counts
-        z.additional_features.setdefault("vox_seg", {})[x.s] = spf.voxelize_segments(idx_query, x.C.shape[0])
-    else:
-        idx_query = z.additional_features["idx_query"][x.s]
-        counts = z.additional_features["counts"][x.s]
+        voxel_index(x.cm, x.s, z, x.C.shape[0])
+    idx_query = z.additional_features["idx_query"][x.s]
+    counts = z.additional_features["counts"][x.s]
     seg = z.additional_features.setdefault("vox_seg", {}).get(x.s)
     inserted_feat = spf.spvoxelize(z.F, idx_query, counts, seg)
     return x.derive(inserted_feat)
@@ -72,28 +91,11 @@ def point_to_voxel(x: SparseTensor, z: PointTensor) -> SparseTensor:
 def voxel_to_point(x: SparseTensor, z: PointTensor, nearest=False) -> PointTensor:
     """reference models/utils.py:68-106."""
     if z.idx_query is None or z.weights is None or z.idx_query.get(x.s) is None or z.weights.get(x.s) is None:
-        off = x.cm.offsets(2, x.s, z.F.device)               # KernelRegion(2, x.s, 1)
-        floored = spf.floor_coords(z.C, x.s)
-        # sphash(floored, off) + sphashquery against sphash(x.C), fused; (8, N) -> (N, 8)
-        idx_query = spf.kernel_map_build(floored, off, x.cm.table(x.s)).transpose(0, 1).contiguous()
-        weights = spf.calc_ti_weights(z.C, idx_query, scale=x.s)
-        if nearest:
-            weights[:, 1:] = 0.0
-            idx_query[:, 1:] = -1
-        seg = spf.devoxelize_segments(idx_query, weights, x.F.shape[0]) if x.F.requires_grad else None
-        z.additional_features.setdefault("devox_seg", {})[x.s] = seg
-        new_feat = spf.spdevoxelize(x.F, idx_query, weights, seg)
-        new_tensor = PointTensor(new_feat, z.C, idx_query=z.idx_query, weights=z.weights)
-        new_tensor.additional_features = z.additional_features
-        new_tensor.idx_query[x.s] = idx_query
-        new_tensor.weights[x.s] = weights
-        z.idx_query[x.s] = idx_query
-        z.weights[x.s] = weights
-    else:
-        segs = z.additional_features.setdefault("devox_seg", {})
-        if segs.get(x.s) is None and x.F.requires_grad:
-            segs[x.s] = spf.devoxelize_segments(z.idx_query.get(x.s), z.weights.get(x.s), x.F.shape[0])
-        new_feat = spf.spdevoxelize(x.F, z.idx_query.get(x.s), z.weights.get(x.s), segs.get(x.s))
-        new_tensor = PointTensor(new_feat, z.C, idx_query=z.idx_query, weights=z.weights)
-        new_tensor.additional_features = z.additional_features
+        point_index(x.cm, x.s, z, x.F.shape[0], nearest=nearest, with_segments=x.F.requires_grad)
+    segs = z.additional_features.setdefault("devox_seg", {})
+    if segs.get(x.s) is None and x.F.requires_grad:
+        segs[x.s] = spf.devoxelize_segments(z.idx_query.get(x.s), z.weights.get(x.s), x.F.shape[0])
+    new_feat = spf.spdevoxelize(x.F, z.idx_query.get(x.s), z.weights.get(x.s), segs.get(x.s))
+    new_tensor = PointTensor(new_feat, z.C, idx_query=z.idx_query, weights=z.weights)
+    new_tensor.additional_features = z.additional_features
     return new_tensor

@@ -170,6 +170,56 @@ def drain(steps):
             return done.value
 
 
+_INDEX_STREAMS = {}
+
+
+def index_stream(device):
+    """The HIP stream coordinate structures are built on when they are built ahead of the forward (SPVCNN.prepare)."""
+    key = (device.type, device.index)
+    if key not in _INDEX_STREAMS:
+        _INDEX_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _INDEX_STREAMS[key]
+
+
+def _device_tensors(obj, seen):
+    """Every CUDA tensor reachable from `obj` through dicts, sequences and plain objects (each once)."""
+    if id(obj) in seen:
+        return
+    seen.add(id(obj))
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            yield obj
+        return
+    if isinstance(obj, dict):
+        for v in obj.values():
+            yield from _device_tensors(v, seen)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _device_tensors(v, seen)
+    elif hasattr(obj, "__dict__") or hasattr(obj, "__slots__"):
+        for name in list(getattr(obj, "__dict__", {})) + list(getattr(obj, "__slots__", ())):
+            v = getattr(obj, name, None)
+            if v is not None and not isinstance(v, (int, float, str, bool, torch.cuda.Event)):
+                yield from _device_tensors(v, seen)
+
+
+class PreparedIndex:
+    """Coordinate structures of one batch built ahead of its forward, on the index stream: the PointTensor (with its point <-> voxel
+    index caches) and the level-0 SparseTensor (with its CoordinateManager)."""
+
+    def __init__(self, z, x0, event):
+        self.z, self.x0, self.event = z, x0, event
+
+    def take(self, stream):
+        """Hand the structures to `stream`: it waits for the build, and every tensor is marked as used there, so the caching allocator
+        (which owns them on the index stream) does not recycle one while a kernel of the consumer is still reading it."""
+        if stream is not None:
+            stream.wait_event(self.event)
+            for t in _device_tensors((self.z, self.x0), set()):
+                t.record_stream(stream)
+        return self.z, self.x0
+
+
 class SparseTensor:
     def __init__(self, feats, coords, stride=1):
         self.F = feats
@@ -178,6 +228,7 @@ class SparseTensor:
         self.coord_maps = {}
         self.kernel_maps = {}
         self.cm = None  # CoordinateManager, attached by initial_voxelize
+        self.prepared = None  # PreparedIndex, attached by SPVCNN.prepare (coordinate structures built ahead of the forward)
 
     def check(self):
         if self.s not in self.coord_maps:

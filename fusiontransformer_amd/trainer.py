@@ -72,7 +72,13 @@ class TrainStep:
         self.fused_loss = True
         self.last = {}
 
-    def __call__(self, data_batch):
+    def __call__(self, data_batch, next_batch=None):
+        """One training step on `data_batch`.  `next_batch` (optional): the batch of the FOLLOWING step; its coordinate structures are
+        built while this step's backward runs (models/_fusion_common.prepare_batch), so the next forward starts at the first
+        convolution.  Measured on MI355X this does NOT pay inside the training loop (batch 4: 128.8 frames/s against 139.7 without;
+        the six host reads of the build then wait behind the backward's kernels instead of behind the previous step's tail, and a
+        helper thread for them, 130.4, contends for the interpreter), so bench.py leaves it off; the entry point is for callers that
+        own an idle moment -- a data-loading worker, an evaluation loop that overlaps the build with the metric."""
         if self.grad_reducer is not None:
             self.grad_reducer.begin_step()   # zeroes the flat gradient buckets (p.grad are views into them)
         else:
@@ -95,6 +101,9 @@ class TrainStep:
                 for m in self.metrics:
                     m.update_dict(preds, data_batch)
         (loss_2d + loss_3d).backward()
+        if next_batch is not None:
+            from .models._fusion_common import prepare_batch
+            prepare_batch(self.model, next_batch)
         if self.grad_reducer is not None:
             self.grad_reducer.finish()
         self.optimizer.step()

@@ -259,6 +259,64 @@ def test_deferred_index_build_equals_lazy_build():
             assert torch.equal(getattr(ka, f), getattr(kb, f)), (key, f)
 
 
+def test_index_built_ahead_is_bit_identical_to_index_built_in_the_forward():
+    """SPVCNN.prepare / prepare_batch / TrainStep(next_batch=...): the coordinate structures of a batch built ahead of its forward, on
+    the index stream, against the same structures built inside the forward -- logits and every gradient bit for bit, in training and
+    in eval, for all three fusion kinds' shared LiDAR backbone; then three optimizer steps over two alternating batches with the
+    prefetch on against the same three steps without it (a structure recycled while the consumer still reads it, or a missing
+    event, shows up as a different bit)."""
+    from fusiontransformer_amd.data.synth import make_batch
+    from fusiontransformer_amd.models._fusion_common import prepare_batch
+    from fusiontransformer_amd.trainer import TrainStep, fusion_losses
+    cfg, oracle, model, _ = _pair("middle", seed=6)
+    batches = [make_batch([8, 9], max_points=3000), make_batch([10], max_points=2500)]
+
+    def run(prepared, train):
+        model.train(train)
+        outs = []
+        for b in batches:
+            pin = product_inputs(b)
+            if prepared:
+                prepare_batch(model, pin)
+                assert pin["lidar"].prepared is not None
+            model.zero_grad(set_to_none=True)
+            torch.manual_seed(0)
+            with torch.set_grad_enabled(train):
+                out = model(pin)
+                assert pin["lidar"].prepared is None          # consumed by the forward
+                if train:
+                    l2, l3 = fusion_losses(out, pin["seg_label"], None, 0.1, True)
+                    (l2 + l3).backward()
+            torch.cuda.synchronize()
+            outs.append(({k: v.detach().clone() for k, v in out.items()},
+                         {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None} if train else {}))
+        return outs
+
+    for train in (True, False):
+        a, b = run(False, train), run(True, train)
+        for (oa, ga), (ob, gb) in zip(a, b):
+            for k in oa:
+                assert torch.equal(oa[k], ob[k]), (train, k)
+            assert ga.keys() == gb.keys()
+            for n in ga:
+                assert torch.equal(ga[n], gb[n]), (train, n)
+
+    def three_steps(prefetch):
+        cfg2, _, m, _ = _pair("middle", seed=7)
+        m.train()
+        step = TrainStep(cfg2, m)
+        pins = [product_inputs(b) for b in batches]
+        for i in range(3):
+            torch.manual_seed(i)
+            step(pins[i % 2], pins[(i + 1) % 2] if prefetch else None)
+        torch.cuda.synchronize()
+        return {n: p.detach().clone() for n, p in m.named_parameters()}
+
+    pa, pb = three_steps(False), three_steps(True)
+    for n in pa:
+        assert torch.equal(pa[n], pb[n]), n
+
+
 def test_bf16_forward_mode_stays_close_to_the_fp32_oracle():
     """BASELINE configs[4] ("bf16 forward"): ViT GEMM operands in bf16.  The reference has no such mode (it is fp32 end
     to end), so the bar is the fp32 oracle with a looser tolerance, stated here: per-point logits within 3e-2 (measured
