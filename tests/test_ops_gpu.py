@@ -397,6 +397,43 @@ def test_batch_norm_matches_torch(env, n, c, relu, res):
     np.testing.assert_allclose(yge.cpu().numpy(), ye.detach().numpy(), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("n,c", [(1, 4), (47, 32), (48 * 31 + 5, 96), (48 * 32, 32), (48 * 33 + 1, 256), (48 * 1024 + 7, 64), (48 * 2048 + 100, 32), (300000, 128),
+                                 (5000, 512)])
+def test_batch_norm_totals_by_the_last_block(env, n, c):
+    """The statistics pass leaves its column totals through "the last block to finish sums" (csrc/ftx_lastblock.h): one group, a partial
+    group, exactly one full group, many groups, the block cap; mean / invstd against float64 numpy, the tickets left clean (the same
+    call repeated, interleaved with another size on the same stream, gives the same bits every time)."""
+    spf, O = env
+    rng = np.random.default_rng(n + c)
+    x = (rng.standard_normal((n, c)) * 3 + 1.5).astype(np.float32)
+    g, b = np.ones(c, np.float32), np.zeros(c, np.float32)
+    xd, gd, bd = dev(x), dev(g), dev(b)
+    other = dev(rng.standard_normal((777, 32)).astype(np.float32))
+    og, ob = torch.ones(32, device="cuda"), torch.zeros(32, device="cuda")
+    outs = []
+    for _ in range(4):
+        rm, rv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+        y = spf.batch_norm(xd, gd, bd, rm, rv, True, 1.0, 1e-5)             # momentum 1: running stats = batch stats
+        spf.batch_norm(other, og, ob, None, None, True, 0.1, 1e-5)          # another launch geometry on the same tickets
+        outs.append((y.clone(), rm.clone(), rv.clone()))
+    for y, rm, rv in outs[1:]:
+        assert torch.equal(y, outs[0][0]) and torch.equal(rm, outs[0][1]) and torch.equal(rv, outs[0][2])
+    x64 = x.astype(np.float64)
+    mean, var = x64.mean(0), x64.var(0)
+    np.testing.assert_allclose(outs[0][1].cpu().numpy(), mean, rtol=2e-6, atol=1e-6)
+    if n > 1:
+        np.testing.assert_allclose(outs[0][2].cpu().numpy(), var * n / (n - 1), rtol=1e-5, atol=1e-6)
+    ref = (x64 - mean) / np.sqrt(var + 1e-5)
+    np.testing.assert_allclose(outs[0][0].cpu().numpy(), ref, rtol=1e-4, atol=2e-5)
+    # and the backward's two totals (d beta, d gamma) through the same path
+    xg = dev(x).requires_grad_(True)
+    gg, bg = dev(g).requires_grad_(True), dev(b).requires_grad_(True)
+    go = rng.standard_normal((n, c)).astype(np.float32)
+    spf.batch_norm(xg, gg, bg, None, None, True, 0.1, 1e-5).backward(dev(go))
+    np.testing.assert_allclose(bg.grad.cpu().numpy(), go.astype(np.float64).sum(0), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(gg.grad.cpu().numpy(), (go.astype(np.float64) * ref).sum(0), rtol=1e-4, atol=2e-2)
+
+
 def test_lift_gather_and_resample_match_golden_rule(env):
     spf, O = env
     rng = np.random.default_rng(8)
