@@ -201,6 +201,8 @@ def main():
     ap.add_argument("--serial-branches", action="store_true",
                     help="issue the image and LiDAR branches back to back on one stream in every step (profiling aid: under rocprofv3 "
                          "each kernel's duration is then its own, as in the roofline block's HIP-event timings)")
+    ap.add_argument("--no-attention-roofline", action="store_true",
+                    help="skip the standalone timing of the attention kernels after the timed region (profiling runs: keeps their launch counts per step exact)")
     ap.add_argument("--index-prefetch", action="store_true",
                     help="build the coordinate structures of batch i+1 during step i (TrainStep(next_batch=...)) instead of inside its own forward; "
                          "measured slower on MI355X (batch 4: 128.8 against 139.7 frames/s), off by default")
@@ -306,7 +308,7 @@ def main():
             "frames_per_sec_per_gpu": round(frames / elapsed / world, 3),
             "roofline": roof,
         }
-        if roof is not None and args.attn == "ftx":
+        if roof is not None and args.attn == "ftx" and not args.no_attention_roofline:
             # The ViT trunk replays as HIP graphs, whose kernels cannot be bracketed by events from the host; the attention kernels are
             # timed here, standalone, at the workload's shape (same launches as inside the graphs), after the timed region.
             # The library entry points are called directly on preallocated buffers, 20 launches between two events, so the figure is

@@ -10,18 +10,24 @@ python bench.py > $O/bench.json 2> $O/bench.err && tail -c 600 $O/bench.json
 python tools/bench_spconv.py > $O/spconv_layer_micro.txt 2>&1; tail -1 $O/spconv_layer_micro.txt
 python tools/bench_spconv.py --what gemm --variant 2 > $O/spconv_layer_micro_pc.txt 2>&1; tail -1 $O/spconv_layer_micro_pc.txt
 python tools/bench_spconv.py --what gemm --split > $O/spconv_layer_micro_split.txt 2>&1; tail -1 $O/spconv_layer_micro_split.txt
+python tools/bench_attn.py > $O/attn_tilings.txt 2>&1; tail -3 $O/attn_tilings.txt
 # N > 1 code path (bucketed overlapped all-reduce, per-rank batches) rehearsed as 2 ranks on this one GPU over gloo: NOT a scaling number
 FTX_DIST_BACKEND=gloo FTX_FORCE_DEVICE=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
   bench.py --gpus 2 --steps 6 --warmup 3 --no-cpu-baseline > $O/bench_2ranks_one_gpu_gloo.json 2> $O/bench_2ranks.err; tail -c 300 $O/bench_2ranks_one_gpu_gloo.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ev_two -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-batch1 --no-nuscenes > $O/prof_two_bench.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ev_two -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-batch1 --no-nuscenes --no-attention-roofline > $O/prof_two_bench.json 2>/dev/null
 cp $(find /tmp/ev_two -name "*kernel_stats.csv" | head -1) $O/rocprof_two_stream_stats.csv
 # serial issue AND an eagerly executed trunk (FTX_VIT_GRAPHS=0: the same kernels, but no capture warm-up passes that would inflate the ViT
 # kernels' per-step counts): every kernel's count and duration is its own
-FTX_VIT_GRAPHS=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ev_ser -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-batch1 --no-nuscenes --serial-branches > $O/prof_serial_bench.json 2>/dev/null
+FTX_VIT_GRAPHS=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ev_ser -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-batch1 --no-nuscenes --no-attention-roofline --serial-branches > $O/prof_serial_bench.json 2>/dev/null
 cp $(find /tmp/ev_ser -name "*kernel_stats.csv" | head -1) $O/rocprof_serial_stats.csv
 (echo "# rocprofv3 --kernel-trace --stats of: FTX_VIT_GRAPHS=0 bench.py --steps 5 --warmup 2 --serial-branches (7 steps; one stream, eager trunk)"; python3 $R/tools/prof_summary.py $O/rocprof_serial_stats.csv 7) > $O/rocprof_serial_summary.txt; head -22 $O/rocprof_serial_summary.txt
 (echo "# rocprofv3 --kernel-trace --stats of: bench.py --steps 5 --warmup 2 (two streams, graphed trunk).  The graph capture replays the trunk 4 extra times, so the"; echo "# ViT rows (library GEMM, attention, layernorm, part of elementwise) are 11/7 of their per-step values here; the serial summary has the exact ones."; python3 $R/tools/prof_summary.py $O/rocprof_two_stream_stats.csv 7) > $O/rocprof_two_stream_summary.txt
+# launches of ONE steady-state step (cut at the loss kernel), batch 1 and batch 4
+rocprofv3 --kernel-trace --output-format csv -d /tmp/ev_k1 -- python3 $R/bench.py --batch 1 --steps 6 --warmup 3 --no-cpu-baseline --no-batch1 --no-nuscenes > /dev/null 2>&1
+python3 $R/tools/step_kernels.py /tmp/ev_k1 > $O/step_kernels_batch1.txt; head -2 $O/step_kernels_batch1.txt
+rocprofv3 --kernel-trace --output-format csv -d /tmp/ev_k4 -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-batch1 --no-nuscenes > /dev/null 2>&1
+python3 $R/tools/step_kernels.py /tmp/ev_k4 > $O/step_kernels_batch4.txt; head -2 $O/step_kernels_batch4.txt
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/ev_f -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch1 --no-nuscenes > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/ev_w -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch1 --no-nuscenes > /dev/null 2>&1
 python3 $R/tools/pmc_hbm.py $(find /tmp/ev_f -name "*counter_collection.csv" | head -1) $(find /tmp/ev_w -name "*counter_collection.csv" | head -1) 3 > $O/pmc_hbm_spconv.json
