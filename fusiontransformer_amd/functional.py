@@ -523,7 +523,7 @@ class _RowsLinear(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = _rows_wgrad(go, x)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = go.sum(0)
+            gb = colsum(go) if go.shape[1] % 4 == 0 else go.sum(0)
         return gx, gw, gb
 
 
@@ -826,6 +826,19 @@ class _ResampleNearest(torch.autograd.Function):
 def resample_nearest(x, size):
     """nn.Upsample(size) (nearest) on NCHW."""
     return _ResampleNearest.apply(x, size[0], size[1])
+
+
+# ---------------------------------------------------------------- column sums (bias gradients)
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    """x (rows, cols) float32 -> (cols,) column sums (float64 accumulation, fixed order): the bias gradient of a Linear."""
+    L = _lib.load()
+    x = req(x.contiguous(), F32, "colsum x", 2)
+    rows, cols = x.shape
+    out = _empty((cols,), F32, x)
+    ws_bytes = _ws_bytes("ftx_colsum_workspace_bytes", rows, cols)
+    ws = _scratch(ws_bytes, x)
+    check(L.ftx_colsum(ptr(x), rows, cols, ptr(out), ptr(ws), ws_bytes, stream()), "ftx_colsum")
+    return out
 
 
 # ---------------------------------------------------------------- ViT self-attention

@@ -32,10 +32,10 @@ def _ones_row(m, like):
 
 
 class _LinearFn(torch.autograd.Function):
-    """y = x W^T + b with the bias gradient as a (1, M) x (M, N) GEMM instead of autograd's sum_to reduction:
-    the column sum of a (2312, 2304..3072) gradient is 3-4x faster as a skinny GEMM on MI355X, and it keeps the
-    trunk replayable as a HIP graph (torch 2.10 / ROCm 7: the reduction kernel's result changes between the first
-    and the later replays of a captured backward, tools/probes/graph_block4.py)."""
+    """y = x W^T + b with the bias gradient from libftx's column-sum kernels (ftx_colsum) instead of autograd's sum_to reduction:
+    that reduction kernel's result changes between the first and the later replays of a captured backward on torch 2.10 / ROCm 7
+    (tools/probes/graph_block4.py), so it cannot stay in a trunk that replays as a HIP graph.  Round 1 used a (1, M) x (M, N) library
+    GEMM for it (14 us per Linear at batch 4, 48 per step); the two column-sum launches take 3-6 us."""
 
     @staticmethod
     def forward(ctx, x, w, b, bf16=False):
@@ -54,7 +54,14 @@ class _LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x2, w = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
-        db = (_ones_row(dy2.shape[0], dy2) @ dy2).view(-1) if ctx.needs_input_grad[2] else None
+        db = None
+        if ctx.needs_input_grad[2]:
+            # column sums by libftx (float64, fixed order); a width that is not a multiple of 4 goes to the skinny GEMM
+            if dy2.shape[1] % 4 == 0:
+                from .. import functional as spf
+                db = spf.colsum(dy2)
+            else:
+                db = (_ones_row(dy2.shape[0], dy2) @ dy2).view(-1)
         if ctx.bf16:
             dy2 = dy2.to(torch.bfloat16)
         dx = (dy2 @ w).float().view(ctx.in_shape) if ctx.needs_input_grad[0] else None

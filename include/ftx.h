@@ -231,6 +231,11 @@ int ftx_bn_eval_fwd(const float *x, const float *residual, const float *gamma, c
  * grad_x (n,c), grad_residual (n,c, may be NULL), grad_gamma (c), grad_beta (c). */
 int ftx_bn_train_bwd(const float *grad_y, const float *x, const float *y, const float *gamma, const float *save_mean, const float *save_invstd, int64_t n, int32_t c, int32_t relu, float *grad_x, float *grad_residual, float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Column sums of a row-major (rows, cols) float32 matrix, float64 accumulation in a fixed order: out (cols).  The bias gradient of
+ * the Linear layers (the reference leaves it to autograd's sum_to: models/transformers.py:16-45, spvcnn.py:164-180).  cols % 4 == 0. */
+size_t ftx_colsum_workspace_bytes(int64_t rows, int32_t cols);
+int ftx_colsum(const float *x, int64_t rows, int32_t cols, float *out, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- ViT self-attention (timm Attention.forward): models/transformers.py:36-37 ----
  * Fused softmax(Q K^T * scale) V on exact-fp32 MFMA; the (t, t) score matrix is never stored. */
 

@@ -434,6 +434,21 @@ def test_batch_norm_totals_by_the_last_block(env, n, c):
     np.testing.assert_allclose(gg.grad.cpu().numpy(), (go.astype(np.float64) * ref).sum(0), rtol=1e-4, atol=2e-2)
 
 
+@pytest.mark.parametrize("rows,cols", [(2312, 768), (2312, 3072), (578, 2304), (81237, 96), (22681, 20), (5, 4), (1, 256), (300, 260), (0, 8)])
+def test_column_sums_match_float64(env, rows, cols):
+    """ftx_colsum (the bias gradient of the Linear layers): against a float64 numpy sum, the same bits on every call."""
+    spf, O = env
+    rng = np.random.default_rng(rows + cols)
+    x = (rng.standard_normal((rows, cols)) * 2 + 0.25).astype(np.float32)
+    xd = dev(x) if rows else torch.empty((0, cols), device="cuda")
+    a, b = spf.colsum(xd), spf.colsum(xd)
+    assert torch.equal(a, b)
+    ref = x.astype(np.float64).sum(0)
+    np.testing.assert_allclose(a.cpu().numpy(), ref, rtol=2e-7, atol=1e-30)   # the float64 total rounded once to float32
+    with pytest.raises(RuntimeError):
+        spf.colsum(torch.zeros((4, 6), device="cuda"))                           # cols must be a multiple of 4: refused by the library
+
+
 def test_lift_gather_and_resample_match_golden_rule(env):
     spf, O = env
     rng = np.random.default_rng(8)
