@@ -9,6 +9,8 @@ the GPU, index tensors are int32 (torchsparse returns int64 and immediately
 `.int()`s them, utils.py:22,51)."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -826,6 +828,94 @@ class _ResampleNearest(torch.autograd.Function):
 def resample_nearest(x, size):
     """nn.Upsample(size) (nearest) on NCHW."""
     return _ResampleNearest.apply(x, size[0], size[1])
+
+
+# ---------------------------------------------------------------- LayerNorm (+ the residual add in front of it)
+_FUSED_LN = os.environ.get("FTX_FUSED_LN", "1") != "0"      # A/B aid: 0 = torch's add + LayerNorm kernels in the ViT blocks
+
+
+def layer_norm_supported(x: torch.Tensor) -> bool:
+    return _FUSED_LN and x.is_cuda and x.dtype == F32 and x.shape[-1] % 256 == 0 and 256 <= x.shape[-1] <= 1024
+
+
+def _ln_forward(x, y, weight, bias, eps):
+    L = _lib.load()
+    shape = x.shape
+    c = shape[-1]
+    x2 = req(x.contiguous().view(-1, c), F32, "layer_norm x", 2)
+    y2 = req(y.contiguous().view(-1, c), F32, "layer_norm y", 2) if y is not None else None
+    if y2 is not None and y2.shape != x2.shape:
+        raise ValueError("add_layer_norm: x and y differ in shape")
+    for t, nm in ((weight, "weight"), (bias, "bias")):
+        req(t, F32, "layer_norm " + nm, 1)
+        if t.shape[0] != c:
+            raise ValueError("layer_norm: parameter length != row length")
+    rows = x2.shape[0]
+    h = torch.empty_like(x2)
+    s = torch.empty_like(x2) if y2 is not None else x2
+    stats = _empty((2, rows), F32, x2)               # row 0: mean, row 1: 1 / sqrt(var + eps)
+    check(L.ftx_add_layernorm_fwd(ptr(x2), ptr(y2), ptr(weight), ptr(bias), float(eps), rows, c, ptr(s) if y2 is not None else 0, ptr(h),
+                                  stats.data_ptr(), stats.data_ptr() + 4 * rows, stream()), "ftx_add_layernorm_fwd")
+    return s, h, stats, shape
+
+
+def _ln_backward(gh, gs, s, weight, stats):
+    L = _lib.load()
+    rows, c = s.shape
+    gh = req(gh.contiguous().view(rows, c), F32, "layer_norm grad", 2)
+    gs = req(gs.contiguous().view(rows, c), F32, "layer_norm residual grad", 2) if gs is not None else None
+    gx = torch.empty_like(s)
+    gparams = _empty((2, c), F32, s)
+    ws_bytes = _ws_bytes("ftx_layernorm_bwd_workspace_bytes", rows, c)
+    ws = _scratch(ws_bytes, s)
+    check(L.ftx_add_layernorm_bwd(ptr(gh), ptr(gs), ptr(s), ptr(weight), stats.data_ptr(), stats.data_ptr() + 4 * rows, rows, c, ptr(gx),
+                                  ptr(gparams), ptr(ws), ws_bytes, stream()), "ftx_add_layernorm_bwd")
+    return gx, gparams
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        s, h, stats, shape = _ln_forward(x, None, weight, bias, eps)
+        ctx.save_for_backward(s, weight, stats)
+        ctx.shape = shape
+        return h.view(shape)
+
+    @staticmethod
+    def backward(ctx, gh):
+        s, weight, stats = ctx.saved_tensors
+        gx, gparams = _ln_backward(gh, None, s, weight, stats)
+        return gx.view(ctx.shape), gparams[0], gparams[1], None
+
+
+class _AddLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, weight, bias, eps):
+        s, h, stats, shape = _ln_forward(x, y, weight, bias, eps)
+        ctx.save_for_backward(s, weight, stats)
+        ctx.shape = shape
+        return s.view(shape), h.view(shape)
+
+    @staticmethod
+    def backward(ctx, gs, gh):
+        s, weight, stats = ctx.saved_tensors
+        if gh is None:                                   # the normalised output was not used: only the sum's gradient passes
+            g = gs if gs is not None else torch.zeros(ctx.shape, dtype=F32, device=s.device)
+            return g, g, None, None, None
+        gx, gparams = _ln_backward(gh, gs, s, weight, stats)
+        gx = gx.view(ctx.shape)
+        return gx, gx, gparams[0], gparams[1], None
+
+
+def layer_norm(x, weight, bias, eps=1e-5):
+    """nn.LayerNorm over the last dimension (256 / 512 / 768 / 1024 floats per row)."""
+    return _LayerNorm.apply(x, weight, bias, eps)
+
+
+def add_layer_norm(x, y, weight, bias, eps=1e-5):
+    """(x + y, LayerNorm(x + y)) in one pass; the backward returns one gradient for both addends: the residual gradient plus the
+    LayerNorm's input gradient, written once."""
+    return _AddLayerNorm.apply(x, y, weight, bias, eps)
 
 
 # ---------------------------------------------------------------- column sums (bias gradients)

@@ -125,9 +125,31 @@ class Block(nn.Module):
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
     def forward(self, x):
-        x = x + self.drop_path(self.attn(self.norm1(x)))
-        x = x + self.drop_path(self.mlp(self.norm2(x)))
-        return x
+        if not self._fused(x):
+            x = x + self.drop_path(self.attn(self.norm1(x)))
+            x = x + self.drop_path(self.mlp(self.norm2(x)))
+            return x
+        r, p = self.chain(x, None)
+        return r + p
+
+    def _fused(self, x):
+        from .. import functional as spf
+        return (spf.layer_norm_supported(x) and type(self.norm1) is nn.LayerNorm and type(self.norm2) is nn.LayerNorm
+                and self.norm1.elementwise_affine and self.norm2.elementwise_affine and self.norm1.bias is not None and self.norm2.bias is not None)
+
+    def chain(self, r, p):
+        """The block on a residual stream held as (r, p) with value r + p (p None: just r); returns it in the same form, (s2, m) with
+        the MLP output m not yet added.  Each LayerNorm runs fused with the add in front of it (libftx ftx_add_layernorm_*): the add
+        of the previous block's MLP output with norm1, the add of the attention output with norm2 -- same arithmetic, a third of the
+        launches (forward: add + LayerNorm -> 1; backward: 3 LayerNorm-gradient kernels + the residual-gradient add -> 2)."""
+        from .. import functional as spf
+        n1, n2 = self.norm1, self.norm2
+        if p is None:
+            s, h = r, spf.layer_norm(r, n1.weight, n1.bias, n1.eps)
+        else:
+            s, h = spf.add_layer_norm(r, p, n1.weight, n1.bias, n1.eps)
+        s2, h2 = spf.add_layer_norm(s, self.drop_path(self.attn(h)), n2.weight, n2.bias, n2.eps)
+        return s2, self.drop_path(self.mlp(h2))
 
 
 class PatchEmbed(nn.Module):
@@ -314,9 +336,14 @@ class _TrunkSegment(nn.Module):
     def forward(self, x):
         if self.embed:
             x = self._trunk._embed(x)
+        if not all(block._fused(x) for block in self.blocks):
+            for block in self.blocks:
+                x = block(x)
+            return x
+        r, p = x, None          # residual stream as (r, p): the add of a block's MLP output runs inside the next block's norm1 kernel
         for block in self.blocks:
-            x = block(x)
-        return x
+            r, p = block.chain(r, p)
+        return r + p
 
 
 def image_2d_distilled_transformer(pretrained=False, **kwargs):

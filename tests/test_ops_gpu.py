@@ -449,6 +449,40 @@ def test_column_sums_match_float64(env, rows, cols):
         spf.colsum(torch.zeros((4, 6), device="cuda"))                           # cols must be a multiple of 4: refused by the library
 
 
+@pytest.mark.parametrize("rows,c,with_add", [(2312, 768, True), (578, 768, False), (37, 256, True), (1, 1024, True), (530, 512, False)])
+def test_fused_add_layer_norm_matches_torch(env, rows, c, with_add):
+    """ftx_add_layernorm_fwd/bwd (the ViT blocks' LayerNorm fused with the residual add in front of it) against torch's add + LayerNorm
+    in float64: both outputs, the shared input gradient (residual gradient + LayerNorm input gradient) and the parameter gradients."""
+    spf, O = env
+    rng = np.random.default_rng(rows * 3 + c)
+    x = (rng.standard_normal((2, rows, c)) * 1.5 + 0.3).astype(np.float32)[:1] if rows == 1 else (rng.standard_normal((rows, c)) * 1.5 + 0.3).astype(np.float32)
+    y = rng.standard_normal(x.shape).astype(np.float32)
+    w, b = rng.uniform(0.5, 1.5, c).astype(np.float32), rng.standard_normal(c).astype(np.float32)
+    gs, gh = rng.standard_normal(x.shape).astype(np.float32), rng.standard_normal(x.shape).astype(np.float32)
+    xo, yo = torch.from_numpy(x).double().requires_grad_(True), torch.from_numpy(y).double().requires_grad_(True)
+    wo, bo = torch.from_numpy(w).double().requires_grad_(True), torch.from_numpy(b).double().requires_grad_(True)
+    so = xo + yo if with_add else xo
+    ho = torch.nn.functional.layer_norm(so, (c,), wo, bo, 1e-6)
+    ((so * torch.from_numpy(gs).double()).sum() * (1.0 if with_add else 0.0) + (ho * torch.from_numpy(gh).double()).sum()).backward()
+    xg, yg = dev(x).requires_grad_(True), dev(y).requires_grad_(True)
+    wg, bg = dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    if with_add:
+        sg, hg = spf.add_layer_norm(xg, yg, wg, bg, 1e-6)
+        np.testing.assert_array_equal(sg.detach().cpu().numpy(), x + y)          # the sum is the plain float32 add
+        ((sg * dev(gs)).sum() + (hg * dev(gh)).sum()).backward()
+        np.testing.assert_allclose(yg.grad.cpu().numpy(), yo.grad.numpy(), rtol=1e-4, atol=2e-5)
+    else:
+        hg = spf.layer_norm(xg, wg, bg, 1e-6)
+        (hg * dev(gh)).sum().backward()
+    np.testing.assert_allclose(hg.detach().cpu().numpy(), ho.detach().numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xo.grad.numpy(), rtol=1e-4, atol=2e-5)
+    scale = max(1.0, float(np.abs(wo.grad.numpy()).max()))
+    np.testing.assert_allclose(wg.grad.cpu().numpy(), wo.grad.numpy(), rtol=1e-4, atol=1e-4 * scale)
+    np.testing.assert_allclose(bg.grad.cpu().numpy(), bo.grad.numpy(), rtol=1e-4, atol=1e-4 * scale)
+    with pytest.raises(RuntimeError):
+        spf.layer_norm(torch.zeros((4, 100), device="cuda"), torch.ones(100, device="cuda"), torch.zeros(100, device="cuda"))   # unsupported row length: refused
+
+
 def test_lift_gather_and_resample_match_golden_rule(env):
     spf, O = env
     rng = np.random.default_rng(8)
