@@ -838,7 +838,7 @@ def layer_norm_supported(x: torch.Tensor) -> bool:
     return _FUSED_LN and x.is_cuda and x.dtype == F32 and x.shape[-1] % 256 == 0 and 256 <= x.shape[-1] <= 1024
 
 
-def _ln_forward(x, y, weight, bias, eps):
+def _ln_forward(x, y, weight, bias, eps, y_bias=None):
     L = _lib.load()
     shape = x.shape
     c = shape[-1]
@@ -846,30 +846,34 @@ def _ln_forward(x, y, weight, bias, eps):
     y2 = req(y.contiguous().view(-1, c), F32, "layer_norm y", 2) if y is not None else None
     if y2 is not None and y2.shape != x2.shape:
         raise ValueError("add_layer_norm: x and y differ in shape")
-    for t, nm in ((weight, "weight"), (bias, "bias")):
+    for t, nm in ((weight, "weight"), (bias, "bias"), (y_bias, "y_bias")):
+        if t is None and nm == "y_bias":
+            continue
         req(t, F32, "layer_norm " + nm, 1)
         if t.shape[0] != c:
             raise ValueError("layer_norm: parameter length != row length")
+    if y_bias is not None and y2 is None:
+        raise ValueError("add_layer_norm: y_bias without y")
     rows = x2.shape[0]
     h = torch.empty_like(x2)
     s = torch.empty_like(x2) if y2 is not None else x2
     stats = _empty((2, rows), F32, x2)               # row 0: mean, row 1: 1 / sqrt(var + eps)
-    check(L.ftx_add_layernorm_fwd(ptr(x2), ptr(y2), ptr(weight), ptr(bias), float(eps), rows, c, ptr(s) if y2 is not None else 0, ptr(h),
+    check(L.ftx_add_layernorm_fwd(ptr(x2), ptr(y2), ptr(y_bias), ptr(weight), ptr(bias), float(eps), rows, c, ptr(s) if y2 is not None else 0, ptr(h),
                                   stats.data_ptr(), stats.data_ptr() + 4 * rows, stream()), "ftx_add_layernorm_fwd")
     return s, h, stats, shape
 
 
-def _ln_backward(gh, gs, s, weight, stats):
+def _ln_backward(gh, gs, s, weight, stats, with_y_bias=False):
     L = _lib.load()
     rows, c = s.shape
     gh = req(gh.contiguous().view(rows, c), F32, "layer_norm grad", 2)
     gs = req(gs.contiguous().view(rows, c), F32, "layer_norm residual grad", 2) if gs is not None else None
     gx = torch.empty_like(s)
-    gparams = _empty((2, c), F32, s)
+    gparams = _empty((3 if with_y_bias else 2, c), F32, s)      # d gamma, d beta (, d y_bias)
     ws_bytes = _ws_bytes("ftx_layernorm_bwd_workspace_bytes", rows, c)
     ws = _scratch(ws_bytes, s)
-    check(L.ftx_add_layernorm_bwd(ptr(gh), ptr(gs), ptr(s), ptr(weight), stats.data_ptr(), stats.data_ptr() + 4 * rows, rows, c, ptr(gx),
-                                  ptr(gparams), ptr(ws), ws_bytes, stream()), "ftx_add_layernorm_bwd")
+    check(L.ftx_add_layernorm_bwd(ptr(gh), ptr(gs), ptr(s), ptr(weight), stats.data_ptr(), stats.data_ptr() + 4 * rows, rows, c, int(with_y_bias),
+                                  ptr(gx), ptr(gparams), ptr(ws), ws_bytes, stream()), "ftx_add_layernorm_bwd")
     return gx, gparams
 
 
@@ -890,10 +894,10 @@ class _LayerNorm(torch.autograd.Function):
 
 class _AddLayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, y, weight, bias, eps):
-        s, h, stats, shape = _ln_forward(x, y, weight, bias, eps)
+    def forward(ctx, x, y, y_bias, weight, bias, eps):
+        s, h, stats, shape = _ln_forward(x, y, weight, bias, eps, y_bias)
         ctx.save_for_backward(s, weight, stats)
-        ctx.shape = shape
+        ctx.shape, ctx.with_y_bias = shape, y_bias is not None
         return s.view(shape), h.view(shape)
 
     @staticmethod
@@ -901,10 +905,11 @@ class _AddLayerNorm(torch.autograd.Function):
         s, weight, stats = ctx.saved_tensors
         if gh is None:                                   # the normalised output was not used: only the sum's gradient passes
             g = gs if gs is not None else torch.zeros(ctx.shape, dtype=F32, device=s.device)
-            return g, g, None, None, None
-        gx, gparams = _ln_backward(gh, gs, s, weight, stats)
+            gyb = colsum(g.reshape(-1, g.shape[-1])) if ctx.with_y_bias else None
+            return g, g, gyb, None, None, None
+        gx, gparams = _ln_backward(gh, gs, s, weight, stats, ctx.with_y_bias)
         gx = gx.view(ctx.shape)
-        return gx, gx, gparams[0], gparams[1], None
+        return gx, gx, (gparams[2] if ctx.with_y_bias else None), gparams[0], gparams[1], None
 
 
 def layer_norm(x, weight, bias, eps=1e-5):
@@ -912,10 +917,11 @@ def layer_norm(x, weight, bias, eps=1e-5):
     return _LayerNorm.apply(x, weight, bias, eps)
 
 
-def add_layer_norm(x, y, weight, bias, eps=1e-5):
-    """(x + y, LayerNorm(x + y)) in one pass; the backward returns one gradient for both addends: the residual gradient plus the
-    LayerNorm's input gradient, written once."""
-    return _AddLayerNorm.apply(x, y, weight, bias, eps)
+def add_layer_norm(x, y, weight, bias, eps=1e-5, y_bias=None):
+    """(s, LayerNorm(s)) with s = x + y in one pass; the backward returns one gradient for both addends: the residual gradient plus the
+    LayerNorm's input gradient, written once.  `y_bias`: y is a Linear's output computed WITHOUT its bias, s = x + (y + y_bias); the
+    bias gradient then comes out of the same backward pass (no column-sum launches for that Linear)."""
+    return _AddLayerNorm.apply(x, y, y_bias, weight, bias, eps)
 
 
 # ---------------------------------------------------------------- column sums (bias gradients)

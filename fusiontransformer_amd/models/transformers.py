@@ -39,6 +39,7 @@ class _LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, bf16=False):
+        # b None: the caller adds the bias itself (Block.chain hands it to the fused add + LayerNorm that consumes this output)
         x2 = x.reshape(-1, x.shape[-1])
         ctx.in_shape, ctx.bf16 = x.shape, bool(bf16)
         if bf16:
@@ -46,9 +47,11 @@ class _LinearFn(torch.autograd.Function):
             # path, result and bias add in fp32; the two backward GEMMs run the same way, the bias gradient stays fp32
             x2, w = x2.to(torch.bfloat16), w.to(torch.bfloat16)
             ctx.save_for_backward(x2, w)
-            return (x2 @ w.t()).float().add_(b).view(*x.shape[:-1], w.shape[0])
+            y = (x2 @ w.t()).float()
+            return (y.add_(b) if b is not None else y).view(*x.shape[:-1], w.shape[0])
         ctx.save_for_backward(x2, w)
-        return torch.addmm(b, x2, w.t()).view(*x.shape[:-1], w.shape[0])
+        y = torch.addmm(b, x2, w.t()) if b is not None else x2 @ w.t()
+        return y.view(*x.shape[:-1], w.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
@@ -69,10 +72,33 @@ class _LinearFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
-def _linear(x, lin):
+class _BatchBroadcast(torch.autograd.Function):
+    """p (1, ...) -> p expanded over a batch of b; the gradient (the sum over the batch) by ftx_colsum instead of autograd's sum_to
+    reduction, which does not replay reliably inside a captured backward (see _LinearFn)."""
+
+    @staticmethod
+    def forward(ctx, p, b):
+        ctx.pshape = p.shape
+        return p.expand(b, *p.shape[1:])
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import functional as spf
+        b = g.shape[0]
+        g2 = g.reshape(b, -1)
+        if g2.is_cuda and g2.dtype == torch.float32 and g2.shape[1] % 4 == 0:
+            return spf.colsum(g2).view(ctx.pshape), None
+        return g2.sum(0).view(ctx.pshape), None
+
+
+def _over_batch(p, b):
+    return _BatchBroadcast.apply(p, b) if p.is_cuda else p.expand(b, *p.shape[1:])
+
+
+def _linear(x, lin, with_bias=True):
     if lin.bias is None or not x.is_cuda:
-        return F.linear(x, lin.weight, lin.bias)
-    return _LinearFn.apply(x, lin.weight, lin.bias, getattr(lin, "ftx_bf16", False))
+        return F.linear(x, lin.weight, lin.bias if with_bias else None)
+    return _LinearFn.apply(x, lin.weight, lin.bias if with_bias else None, getattr(lin, "ftx_bf16", False))
 
 
 class Mlp(nn.Module):
@@ -83,8 +109,8 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features, in_features)
         self.drop = nn.Dropout(drop)
 
-    def forward(self, x):
-        return self.drop(_linear(self.drop(self.act(_linear(x, self.fc1))), self.fc2))
+    def forward(self, x, with_fc2_bias=True):
+        return self.drop(_linear(self.drop(self.act(_linear(x, self.fc1))), self.fc2, with_fc2_bias))
 
 
 class Attention(nn.Module):
@@ -99,7 +125,7 @@ class Attention(nn.Module):
         self.proj_drop = nn.Dropout(proj_drop)
         self.attn_impl = "ftx"
 
-    def forward(self, x):
+    def forward(self, x, with_proj_bias=True):
         B, N, C = x.shape
         qkv = _linear(x, self.qkv)
         if self.attn_impl == "ftx":
@@ -112,7 +138,7 @@ class Attention(nn.Module):
             attn = attn.softmax(dim=-1)
             attn = self.attn_drop(attn)
             x = (attn @ v).transpose(1, 2).reshape(B, N, C)
-        return self.proj_drop(_linear(x, self.proj))
+        return self.proj_drop(_linear(x, self.proj, with_proj_bias))
 
 
 class Block(nn.Module):
@@ -129,27 +155,35 @@ class Block(nn.Module):
             x = x + self.drop_path(self.attn(self.norm1(x)))
             x = x + self.drop_path(self.mlp(self.norm2(x)))
             return x
-        r, p = self.chain(x, None)
-        return r + p
+        return _materialize(*self.chain(x, None, None))
 
     def _fused(self, x):
         from .. import functional as spf
         return (spf.layer_norm_supported(x) and type(self.norm1) is nn.LayerNorm and type(self.norm2) is nn.LayerNorm
-                and self.norm1.elementwise_affine and self.norm2.elementwise_affine and self.norm1.bias is not None and self.norm2.bias is not None)
+                and self.norm1.elementwise_affine and self.norm2.elementwise_affine and self.norm1.bias is not None and self.norm2.bias is not None
+                and self.attn.proj.bias is not None and self.mlp.fc2.bias is not None and self.attn.proj_drop.p == 0.0 and self.mlp.drop.p == 0.0
+                and isinstance(self.drop_path, nn.Identity))
 
-    def chain(self, r, p):
-        """The block on a residual stream held as (r, p) with value r + p (p None: just r); returns it in the same form, (s2, m) with
-        the MLP output m not yet added.  Each LayerNorm runs fused with the add in front of it (libftx ftx_add_layernorm_*): the add
-        of the previous block's MLP output with norm1, the add of the attention output with norm2 -- same arithmetic, a third of the
-        launches (forward: add + LayerNorm -> 1; backward: 3 LayerNorm-gradient kernels + the residual-gradient add -> 2)."""
+    def chain(self, r, p, pb):
+        """The block on a residual stream held as (r, p, pb) with value r + (p + pb) (p None: just r; pb: the bias that the Linear
+        which produced p did NOT add); returns it in the same form, (s2, m, fc2.bias) with the MLP output m not yet added and
+        computed without its bias (`_materialize` turns the triple into one tensor, in the same rounding order).  Each LayerNorm runs fused with the add in front of it (libftx ftx_add_layernorm_*): the
+        add of the previous block's MLP output with norm1, the add of the attention output with norm2 -- same arithmetic in the same
+        rounding order, a third of the launches (forward: add + LayerNorm -> 1; backward: 3 LayerNorm-gradient kernels + the
+        residual-gradient add + the column sums for the proj / fc2 bias gradients -> 2)."""
         from .. import functional as spf
         n1, n2 = self.norm1, self.norm2
         if p is None:
             s, h = r, spf.layer_norm(r, n1.weight, n1.bias, n1.eps)
         else:
-            s, h = spf.add_layer_norm(r, p, n1.weight, n1.bias, n1.eps)
-        s2, h2 = spf.add_layer_norm(s, self.drop_path(self.attn(h)), n2.weight, n2.bias, n2.eps)
-        return s2, self.drop_path(self.mlp(h2))
+            s, h = spf.add_layer_norm(r, p, n1.weight, n1.bias, n1.eps, y_bias=pb)
+        s2, h2 = spf.add_layer_norm(s, self.attn(h, with_proj_bias=False), n2.weight, n2.bias, n2.eps, y_bias=self.attn.proj.bias)
+        return s2, self.mlp(h2, with_fc2_bias=False), self.mlp.fc2.bias
+
+
+def _materialize(r, p, pb):
+    """r + (p + pb): the residual stream of Block.chain as one tensor (bias first, as a GEMM's bias epilogue rounds it)."""
+    return r + (p + pb)
 
 
 class PatchEmbed(nn.Module):
@@ -168,7 +202,10 @@ class PatchEmbed(nn.Module):
         ph, pw = self.patch_size
         gh, gw = H // ph, W // pw
         patches = x.reshape(B, C, gh, ph, gw, pw).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * ph * pw)
-        return self.norm(F.linear(patches, self.proj.weight.view(self.proj.out_channels, -1), self.proj.bias))
+        w2 = self.proj.weight.view(self.proj.out_channels, -1)
+        if x.is_cuda and self.proj.bias is not None and self.proj.out_channels % 4 == 0:
+            return self.norm(_LinearFn.apply(patches, w2, self.proj.bias, False))    # bias gradient by ftx_colsum, not autograd's sum_to (see _LinearFn)
+        return self.norm(F.linear(patches, w2, self.proj.bias))
 
 
 class Image2DTransformer(nn.Module):
@@ -218,12 +255,13 @@ class Image2DTransformer(nn.Module):
 
     def _embed(self, x):
         x = self.patch_embed(x)
-        cls_token = self.cls_token.expand(x.shape[0], -1, -1)
+        b = x.shape[0]
+        cls_token = _over_batch(self.cls_token, b)
         if self.dist_token is None:
             x = torch.cat((cls_token, x), dim=1)
         else:
-            x = torch.cat((cls_token, self.dist_token.expand(x.shape[0], -1, -1), x), dim=1)
-        return self.pos_drop(x + self.pos_embed)
+            x = torch.cat((cls_token, _over_batch(self.dist_token, b), x), dim=1)
+        return self.pos_drop(x + _over_batch(self.pos_embed, b))
 
     def forward_blocks(self, x: torch.Tensor, on_block=None) -> Dict[str, torch.Tensor]:
         """reference models/transformers.py:16-45: every block's output, cls/dist tokens stripped.
@@ -340,10 +378,10 @@ class _TrunkSegment(nn.Module):
             for block in self.blocks:
                 x = block(x)
             return x
-        r, p = x, None          # residual stream as (r, p): the add of a block's MLP output runs inside the next block's norm1 kernel
+        r, p, pb = x, None, None    # residual stream as (r, p, pb): the add of a block's MLP output (and of fc2's bias) runs inside the next block's norm1 kernel
         for block in self.blocks:
-            r, p = block.chain(r, p)
-        return r + p
+            r, p, pb = block.chain(r, p, pb)
+        return _materialize(r, p, pb)
 
 
 def image_2d_distilled_transformer(pretrained=False, **kwargs):

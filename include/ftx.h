@@ -233,12 +233,13 @@ int ftx_bn_train_bwd(const float *grad_y, const float *x, const float *y, const 
 
 /* ---- LayerNorm of the ViT blocks, fused with the residual add in front of it (timm Block.forward: models/transformers.py:16-45) ----
  * forward: s = x + y (y may be NULL: then s_out is not written and s = x), h = (s - mean) * rstd * gamma + beta over rows of c floats,
- * c in {256, 512, 768, 1024}; mean / rstd (rows) are outputs for the backward. */
-int ftx_add_layernorm_fwd(const float *x, const float *y, const float *gamma, const float *beta, float eps, int64_t rows, int32_t c, float *s_out, float *h_out, float *mean, float *rstd, void *stream);
+ * c in {256, 512, 768, 1024}; mean / rstd (rows) are outputs for the backward.  y_bias (c, may be NULL): y is the output of a Linear
+ * computed WITHOUT its bias, s = x + (y + y_bias) -- the rounding order of the GEMM's own bias epilogue. */
+int ftx_add_layernorm_fwd(const float *x, const float *y, const float *y_bias, const float *gamma, const float *beta, float eps, int64_t rows, int32_t c, float *s_out, float *h_out, float *mean, float *rstd, void *stream);
 /* backward: grad_x (rows, c) = grad_s (may be NULL) + d h / d s applied to grad_h -- the gradient of BOTH x and y;
- * grad_params (2, c) = d gamma, d beta (float64 accumulation, fixed order). */
+ * grad_params (2 or 3, c) = d gamma, d beta and, with_y_bias != 0, d y_bias = the column sums of grad_x (float64 accumulation, fixed order). */
 size_t ftx_layernorm_bwd_workspace_bytes(int64_t rows, int32_t c);
-int ftx_add_layernorm_bwd(const float *grad_h, const float *grad_s, const float *s, const float *gamma, const float *mean, const float *rstd, int64_t rows, int32_t c, float *grad_x, float *grad_params, void *workspace, size_t workspace_bytes, void *stream);
+int ftx_add_layernorm_bwd(const float *grad_h, const float *grad_s, const float *s, const float *gamma, const float *mean, const float *rstd, int64_t rows, int32_t c, int32_t with_y_bias, float *grad_x, float *grad_params, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Column sums of a row-major (rows, cols) float32 matrix, float64 accumulation in a fixed order: out (cols).  The bias gradient of
  * the Linear layers (the reference leaves it to autograd's sum_to: models/transformers.py:16-45, spvcnn.py:164-180).  cols % 4 == 0. */

@@ -461,16 +461,23 @@ def test_fused_add_layer_norm_matches_torch(env, rows, c, with_add):
     gs, gh = rng.standard_normal(x.shape).astype(np.float32), rng.standard_normal(x.shape).astype(np.float32)
     xo, yo = torch.from_numpy(x).double().requires_grad_(True), torch.from_numpy(y).double().requires_grad_(True)
     wo, bo = torch.from_numpy(w).double().requires_grad_(True), torch.from_numpy(b).double().requires_grad_(True)
-    so = xo + yo if with_add else xo
+    yb = rng.standard_normal(c).astype(np.float32)
+    ybo = torch.from_numpy(yb).double().requires_grad_(True)
+    so = xo + (yo + ybo) if with_add else xo
     ho = torch.nn.functional.layer_norm(so, (c,), wo, bo, 1e-6)
     ((so * torch.from_numpy(gs).double()).sum() * (1.0 if with_add else 0.0) + (ho * torch.from_numpy(gh).double()).sum()).backward()
     xg, yg = dev(x).requires_grad_(True), dev(y).requires_grad_(True)
     wg, bg = dev(w).requires_grad_(True), dev(b).requires_grad_(True)
     if with_add:
-        sg, hg = spf.add_layer_norm(xg, yg, wg, bg, 1e-6)
-        np.testing.assert_array_equal(sg.detach().cpu().numpy(), x + y)          # the sum is the plain float32 add
+        ybg = dev(yb).requires_grad_(True)
+        sg, hg = spf.add_layer_norm(xg, yg, wg, bg, 1e-6, y_bias=ybg)
+        np.testing.assert_array_equal(sg.detach().cpu().numpy(), x + (y + yb))   # the sum is the plain float32 adds, bias first
+        s_plain, h_plain = spf.add_layer_norm(dev(x), dev(y + yb), wg.detach(), bg.detach(), 1e-6)
+        assert torch.equal(s_plain, sg) and torch.equal(h_plain, hg)              # with or without the bias handed over: same bits
         ((sg * dev(gs)).sum() + (hg * dev(gh)).sum()).backward()
         np.testing.assert_allclose(yg.grad.cpu().numpy(), yo.grad.numpy(), rtol=1e-4, atol=2e-5)
+        ysc = max(1.0, float(np.abs(ybo.grad.numpy()).max()))
+        np.testing.assert_allclose(ybg.grad.cpu().numpy(), ybo.grad.numpy(), rtol=1e-4, atol=1e-5 * ysc)
     else:
         hg = spf.layer_norm(xg, wg, bg, 1e-6)
         (hg * dev(gh)).sum().backward()
