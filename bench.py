@@ -20,6 +20,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver (set before the runtime starts)
+
 import numpy as np
 import torch
 import torch.distributed as dist

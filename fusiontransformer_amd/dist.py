@@ -21,6 +21,8 @@ from __future__ import annotations
 
 import os
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL / cross-process device memory on this driver
+
 import torch
 import torch.distributed as dist
 
