@@ -70,6 +70,9 @@ SIGNATURES = {
     "ftx_bn_workspace_bytes": (_sz, [_i64, _i32]),
     "ftx_bn_train_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ftx_bn_eval_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i32, _i32, _vp, _vp]),
+    "ftx_adam_chunk_elements": (_i32, []),
+    "ftx_adam_tensor_bytes": (_i32, []),
+    "ftx_adam_step": (C.c_int, [_vp, _vp, _vp, _i32, C.c_double, C.c_double, _f32, _f32, _vp]),
     "ftx_add_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _f32, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ftx_layernorm_bwd_workspace_bytes": (_sz, [_i64, _i32]),
     "ftx_add_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),

@@ -10,6 +10,8 @@ SemanticTrainer.py:158-178, Adam step.  Differences, all behaviour-preserving:
     losses and the IoU confusion matrices stay on the device."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -47,7 +49,11 @@ def build_optimizer(cfg, model):
     """common/solver/build.py:7-20: getattr(torch.optim, TYPE)(params, lr, weight_decay)."""
     params = [p for p in model.parameters() if p.requires_grad]
     kwargs = dict(lr=cfg.OPTIMIZER.BASE_LR, weight_decay=cfg.OPTIMIZER.WEIGHT_DECAY)
-    if cfg.OPTIMIZER.TYPE in ("Adam", "AdamW") and params and params[0].is_cuda:
+    on_gpu = bool(params) and params[0].is_cuda
+    if cfg.OPTIMIZER.TYPE == "Adam" and on_gpu and os.environ.get("FTX_ADAM", "1") != "0":
+        from .optim import Adam      # torch.optim.Adam's rule and state layout, stepped by one libftx launch (csrc/ftx_optim.hip)
+        return Adam(params, **kwargs)
+    if cfg.OPTIMIZER.TYPE in ("Adam", "AdamW") and on_gpu:
         kwargs["fused"] = True  # same update rule, one multi-tensor kernel instead of ~10 passes over 108 M parameters
     return getattr(torch.optim, cfg.OPTIMIZER.TYPE)(params, **kwargs)
 

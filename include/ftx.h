@@ -231,6 +231,18 @@ int ftx_bn_eval_fwd(const float *x, const float *residual, const float *gamma, c
  * grad_x (n,c), grad_residual (n,c, may be NULL), grad_gamma (c), grad_beta (c). */
 int ftx_bn_train_bwd(const float *grad_y, const float *x, const float *y, const float *gamma, const float *save_mean, const float *save_invstd, int64_t n, int32_t c, int32_t relu, float *grad_x, float *grad_residual, float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- optimizer step: torch.optim.Adam (L2 weight decay, no amsgrad) over every parameter tensor in one launch ----
+ * (common/solver/build.py:7-20 builds the optimizer, modules/SemanticTrainer.py:141-209 steps it once per batch.)
+ * table: n_tensors records of ftx_adam_tensor_bytes() bytes in DEVICE memory, little-endian, in this order:
+ *   float *param; float *exp_avg; float *exp_avg_sq; const float *grad (NULL: tensor skipped this step); int64 numel;
+ *   float step_size = lr / (1 - beta1^t); float inv_bc2_sqrt = 1 / sqrt(1 - beta2^t).
+ * chunk_tensor / chunk_offset (n_chunks, device): chunk c covers elements [offset, offset + ftx_adam_chunk_elements()) of tensor
+ * chunk_tensor[c].  Update per element: g += wd*p; m += (1-beta1)*(g-m); v = beta2*v + (1-beta2)*g*g;
+ * p -= step_size * m / (sqrt(v) * inv_bc2_sqrt + eps).  beta1 / beta2 are doubles: 1 - beta is formed in double and then rounded, as torch does. */
+int32_t ftx_adam_chunk_elements(void);
+int32_t ftx_adam_tensor_bytes(void);
+int ftx_adam_step(const void *table, const int32_t *chunk_tensor, const int64_t *chunk_offset, int32_t n_chunks, double beta1, double beta2, float eps, float weight_decay, void *stream);
+
 /* ---- LayerNorm of the ViT blocks, fused with the residual add in front of it (timm Block.forward: models/transformers.py:16-45) ----
  * forward: s = x + y (y may be NULL: then s_out is not written and s = x), h = (s - mean) * rstd * gamma + beta over rows of c floats,
  * c in {256, 512, 768, 1024}; mean / rstd (rows) are outputs for the backward.  y_bias (c, may be NULL): y is the output of a Linear

@@ -490,6 +490,47 @@ def test_fused_add_layer_norm_matches_torch(env, rows, c, with_add):
         spf.layer_norm(torch.zeros((4, 100), device="cuda"), torch.ones(100, device="cuda"), torch.zeros(100, device="cuda"))   # unsupported row length: refused
 
 
+def test_adam_one_launch_matches_torch_adam(env):
+    """fusiontransformer_amd.optim.Adam (csrc/ftx_optim.hip) against torch.optim.Adam over 6 steps on tensors of awkward sizes (one
+    element, a 16 K chunk boundary, a length that is not a multiple of 4, a parameter that gets no gradient in some steps), with weight
+    decay; parameters and both moments after every step, and the state_dict round trip into a torch.optim.Adam and back."""
+    spf, O = env
+    from fusiontransformer_amd.optim import Adam
+    rng = np.random.default_rng(21)
+    shapes = [(1,), (16384,), (16385,), (333, 7), (3, 64, 96), (70001,), (5,)]
+    base = [rng.standard_normal(sh).astype(np.float32) for sh in shapes]
+    pa = [torch.nn.Parameter(dev(b.copy())) for b in base]
+    pb = [torch.nn.Parameter(dev(b.copy())) for b in base]
+    oa = Adam(pa, lr=3e-3, weight_decay=5e-4)
+    ob = torch.optim.Adam(pb, lr=3e-3, weight_decay=5e-4)
+    for step in range(6):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i == 4 and step in (1, 2):
+                a.grad = b.grad = None                  # this parameter sits two steps out: its step counter must lag
+                continue
+            g = dev(rng.standard_normal(shapes[i]).astype(np.float32))
+            a.grad, b.grad = g.clone(), g.clone()
+        if step == 3:                                   # a non-contiguous gradient
+            pa[3].grad = pa[3].grad.t().contiguous().t()
+        oa.step(); ob.step()
+        for a, b in zip(pa, pb):
+            np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
+            np.testing.assert_allclose(oa.state[a]["exp_avg"].cpu().numpy(), ob.state[b]["exp_avg"].cpu().numpy(), rtol=2e-6, atol=1e-8)
+            np.testing.assert_allclose(oa.state[a]["exp_avg_sq"].cpu().numpy(), ob.state[b]["exp_avg_sq"].cpu().numpy(), rtol=2e-6, atol=1e-10)
+    sd = oa.state_dict()
+    assert [int(sd["state"][i]["step"]) for i in range(len(pa))] == [int(ob.state_dict()["state"][i]["step"]) for i in range(len(pb))]
+    oc = torch.optim.Adam(pa, lr=3e-3, weight_decay=5e-4)
+    oc.load_state_dict(sd)                              # our state continues in torch's optimizer ...
+    od = Adam(pb, lr=3e-3, weight_decay=5e-4)
+    od.load_state_dict(ob.state_dict())                 # ... and torch's in ours
+    for a, b in zip(pa, pb):
+        g = dev(rng.standard_normal(a.shape).astype(np.float32))
+        a.grad, b.grad = g.clone(), g.clone()
+    oc.step(); od.step()
+    for a, b in zip(pa, pb):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
+
+
 def test_lift_gather_and_resample_match_golden_rule(env):
     spf, O = env
     rng = np.random.default_rng(8)
