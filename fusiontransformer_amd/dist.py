@@ -90,14 +90,15 @@ class GradReducer:
         if cur:
             groups.append(cur)
         for g in groups:
-            flat = torch.zeros(sum(p.numel() for p in g), dtype=g[0].dtype, device=g[0].device)
+            pad4 = lambda n: (n + 3) & ~3     # every gradient view starts on a 16-byte boundary (vector loads in ftx_adam_step)
+            flat = torch.zeros(sum(pad4(p.numel()) for p in g), dtype=g[0].dtype, device=g[0].device)
             off = 0
             for p in g:
                 view = flat[off:off + p.numel()].view_as(p)
                 if p.grad is not None:
                     view.copy_(p.grad)
                 p.grad = view
-                off += p.numel()
+                off += pad4(p.numel())
             b = _Bucket(g, flat)
             for p in g:
                 self.bucket_of[p] = len(self.buckets)
