@@ -10,7 +10,10 @@ def cat(name):
     if 'attn_' in name: return 'ftx attention'
     if name.startswith('Cijk'): return 'hipBLASLt GEMM (Cijk)'
     if 'bn_' in name: return 'ftx bn'
-    if 'voxelize' in name: return 'ftx vox/devox'
+    if 'voxelize' in name or 'segment_reduce' in name or 'seg_prepare' in name: return 'ftx vox/devox (incl. sorted-segment reduces)'
+    if 'add_ln_' in name or 'ln_params_final' in name or 'colsum_' in name: return 'ftx layernorm / column sums'
+    if 'adam_kernel' in name: return 'ftx adam'
+    if 'loss_' in name or name.startswith('sd_') or 'sd_' in name.split('(')[0]: return 'ftx loss / sample_down'
     if 'lift' in name or 'resample' in name: return 'ftx lift/resample'
     if any(k in name for k in ['hash', 'table_', 'kernel_map', 'count_kernel', 'iota', 'gather_coords', 'downsample', 'trilinear', 'floor_coords',
                                'fill_m1', 'koff_kernel', 'pairs_scatter', 'rocprim', 'sorted_rank']): return 'ftx index'
