@@ -19,6 +19,12 @@ StreamScratch stream_scratch(hipStream_t st) {
   auto it = pool.find(st);
   if (it != pool.end()) return it->second;
   StreamScratch sc{nullptr, nullptr};
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+    set_error("stream_scratch: first use of a stream inside a capture (run the op once on that stream before capturing)");
+    return sc;
+  }
+  (void)hipGetLastError();
   const size_t cbytes = 512 * ((sizeof(uint32_t) * (1 + LB_MAX_GROUPS) + 511) / 512);
   const size_t gbytes = sizeof(double) * (size_t)LB_MAX_GROUPS * 2 * LB_MAX_COLS;
   char *base = nullptr;

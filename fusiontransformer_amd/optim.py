@@ -70,8 +70,9 @@ class Adam(torch.optim.Adam):
             return False
         if isinstance(group["lr"], torch.Tensor):
             return False
+        dev = group["params"][0].device if group["params"] else None
         for p in group["params"]:
-            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+            if not (p.is_cuda and p.device == dev and p.dtype == torch.float32 and p.is_contiguous()):
                 return False
             if p.grad is not None and (p.grad.is_sparse or p.grad.dtype != torch.float32):
                 return False
