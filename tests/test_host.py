@@ -123,3 +123,40 @@ def test_scan_file_round_trip_and_untrusted_pickles_are_refused(tmp_path):
     write_scan(bad, dict(scan, points=scan["points"][:10]))
     with pytest.raises(ValueError):
         read_scan(bad)
+
+
+def test_adam_on_cpu_parameters_is_torch_adam():
+    """fusiontransformer_amd.optim.Adam hands anything its kernel does not cover (here: CPU parameters) to torch.optim.Adam.step, and
+    keeps torch's state_dict layout."""
+    import torch
+    from fusiontransformer_amd.optim import Adam
+    torch.manual_seed(0)
+    a = [torch.nn.Parameter(torch.randn(7, 3)), torch.nn.Parameter(torch.randn(5))]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    oa, ob = Adam(a, lr=1e-2, weight_decay=1e-3), torch.optim.Adam(b, lr=1e-2, weight_decay=1e-3)
+    for _ in range(3):
+        for p, q in zip(a, b):
+            g = torch.randn_like(p)
+            p.grad, q.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+    for p, q in zip(a, b):
+        assert torch.equal(p, q)
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert sa["state"].keys() == sb["state"].keys()
+    for k in sa["state"]:
+        assert sa["state"][k].keys() == sb["state"][k].keys()
+        assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"]) == 3.0
+
+
+def test_prepare_batch_is_a_no_op_off_the_gpu():
+    """prepare_batch / SPVCNN.prepare build coordinate structures ahead only for device tensors; a CPU batch passes through untouched
+    (the forward would fail loudly later: the product has no CPU path)."""
+    import torch
+    from fusiontransformer_amd.models._fusion_common import prepare_batch
+    from fusiontransformer_amd.models.build import build_model
+    from fusiontransformer_amd.sparse import SparseTensor
+    from tests.helpers import small_cfg
+    model, _, _ = build_model(small_cfg("middle"))
+    lidar = SparseTensor(torch.zeros(4, 4), torch.zeros(4, 4, dtype=torch.int32))
+    d = {"lidar": lidar}
+    assert prepare_batch(model, d) is d and lidar.prepared is None
