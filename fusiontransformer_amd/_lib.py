@@ -64,11 +64,11 @@ SIGNATURES = {
     "ftx_spconv_reduce": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "ftx_spconv_reduce_stats_blocks": (_i32, [_i64, _i32]),
     "ftx_spconv_reduce_stats": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp]),
-    "ftx_bn_train_fwd_totals": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ftx_bn_train_fwd_totals": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ftx_spconv_pairs_wgrad_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "ftx_spconv_pairs_wgrad": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "ftx_bn_workspace_bytes": (_sz, [_i64, _i32]),
-    "ftx_bn_train_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ftx_bn_train_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ftx_bn_eval_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i32, _i32, _vp, _vp]),
     "ftx_adam_chunk_elements": (_i32, []),
     "ftx_adam_tensor_bytes": (_i32, []),
@@ -87,7 +87,7 @@ SIGNATURES = {
     "ftx_fusion_loss_mix": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ftx_project_points": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp]),
     "ftx_eval_scatter_back": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "ftx_bn_train_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ftx_bn_train_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

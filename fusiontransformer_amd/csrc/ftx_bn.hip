@@ -76,11 +76,9 @@ struct BwdOp {
 
 template <class Op>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict__ x, const float *__restrict__ gy,
-                                                         const float *__restrict__ y, const uint8_t *__restrict__ ymask,
-                                                         const float *__restrict__ mean, const float *__restrict__ invstd, int relu,
-                                                         int64_t n, int c, double *part, StreamScratch sc) {
-  // ymask (optional, instead of y): one byte per float4 of the forward output, bit v set where element v was > 0 (written by the
-  // forward apply pass): the ReLU mask at 1/16 of y's bytes
+                                                         const float *__restrict__ y, const float *__restrict__ mean,
+                                                         const float *__restrict__ invstd, int relu, int64_t n, int c,
+                                                         double *part, StreamScratch sc) {
   // part: gridDim.x rows [2][c], then the totals row [2][c] written by the last block to finish (ftx_lastblock.h)
   extern __shared__ double sh[];  // [2][RL][c]
   const int c4 = c >> 2;
@@ -105,25 +103,18 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict
       Op::eval(xv.w, gv.w, yv.w, mu.w, is.w, relu, a, b); s0[3] += a; s1[3] += b;
     };
     const float4 zero4 = make_float4(0, 0, 0, 0);
-    auto load_y = [&](int64_t row, int64_t o) {   // the forward output, or a stand-in with the same sign pattern from the mask byte
-      if (ymask) {
-        const unsigned m = ymask[row * c4 + cg];
-        return make_float4((m & 1u) ? 1.f : 0.f, (m & 2u) ? 1.f : 0.f, (m & 4u) ? 1.f : 0.f, (m & 8u) ? 1.f : 0.f);
-      }
-      return y ? *(const float4 *)&y[o] : zero4;
-    };
     int64_t r = r0 + rl;
     for (; r + RL < r1; r += 2 * RL) {   // two rows per trip: six independent 16-byte loads in flight per thread, summed in row order
       const int64_t o0 = r * c + cg * 4, o1 = (r + RL) * c + cg * 4;
       const float4 xa = *(const float4 *)&x[o0], xb = *(const float4 *)&x[o1];
       const float4 ga = gy ? *(const float4 *)&gy[o0] : zero4, gb = gy ? *(const float4 *)&gy[o1] : zero4;
-      const float4 ya = load_y(r, o0), yb = load_y(r + RL, o1);
+      const float4 ya = y ? *(const float4 *)&y[o0] : zero4, yb = y ? *(const float4 *)&y[o1] : zero4;
       accumulate(xa, ga, ya);
       accumulate(xb, gb, yb);
     }
     for (; r < r1; r += RL) {
       const int64_t o0 = r * c + cg * 4;
-      accumulate(*(const float4 *)&x[o0], gy ? *(const float4 *)&gy[o0] : zero4, load_y(r, o0));
+      accumulate(*(const float4 *)&x[o0], gy ? *(const float4 *)&gy[o0] : zero4, y ? *(const float4 *)&y[o0] : zero4);
     }
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -159,7 +150,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float *__restri
                                                            const float *__restrict__ beta, const double *__restrict__ totals, float eps,
                                                            float momentum, float *__restrict__ running_mean, float *__restrict__ running_var,
                                                            float *__restrict__ save_mean, float *__restrict__ save_invstd, int64_t n, int c,
-                                                           int relu, float *__restrict__ y, uint8_t *__restrict__ ymask) {
+                                                           int relu, float *__restrict__ y) {
   const int c4 = c >> 2;
   const int RL = 256 / c4 > 0 ? 256 / c4 : 1;
   const int cg = threadIdx.x % c4, rl = threadIdx.x / c4;
@@ -195,7 +186,6 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float *__restri
       ov.x += rv.x; ov.y += rv.y; ov.z += rv.z; ov.w += rv.w;
     }
     if (relu) {
-      if (ymask) ymask[r * c4 + cg] = (uint8_t)((ov.x > 0.f ? 1u : 0u) | (ov.y > 0.f ? 2u : 0u) | (ov.z > 0.f ? 4u : 0u) | (ov.w > 0.f ? 8u : 0u));
       ov.x = ov.x > 0.f ? ov.x : 0.f; ov.y = ov.y > 0.f ? ov.y : 0.f;
       ov.z = ov.z > 0.f ? ov.z : 0.f; ov.w = ov.w > 0.f ? ov.w : 0.f;
     }
@@ -232,8 +222,7 @@ static size_t bn_partial_lds(int c) {
 
 extern "C" int ftx_bn_train_fwd(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean,
                                 float *running_var, float momentum, float eps, int64_t n, int32_t c, int32_t relu, float *y,
-                                uint8_t *relu_mask, float *save_mean, float *save_invstd, void *workspace, size_t workspace_bytes,
-                                void *stream) {
+                                float *save_mean, float *save_invstd, void *workspace, size_t workspace_bytes, void *stream) {
   int rc = bn_check("ftx_bn_train_fwd", n, c);
   if (rc != FTX_OK) return rc;
   FTX_REQUIRE(n >= 1, "ftx_bn_train_fwd: needs at least one row");
@@ -248,9 +237,9 @@ extern "C" int ftx_bn_train_fwd(const float *x, const float *residual, const flo
   if (!sc.counters) return FTX_ELAUNCH;
   const int nb = bn_blocks(n);
   double *part = (double *)workspace;
-  bn_partial_kernel<FwdOp><<<nb, 256, bn_partial_lds(c), st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n, c, part, sc);
+  bn_partial_kernel<FwdOp><<<nb, 256, bn_partial_lds(c), st>>>(x, nullptr, nullptr, nullptr, nullptr, 0, n, c, part, sc);
   bn_apply_fwd_kernel<<<bn_apply_grid(n, c), 256, 0, st>>>(x, residual, gamma, beta, part + (size_t)nb * 2 * c, eps, momentum, running_mean,
-                                                           running_var, save_mean, save_invstd, n, c, relu, y, relu_mask);
+                                                           running_var, save_mean, save_invstd, n, c, relu, y);
   return check_launch("ftx_bn_train_fwd");
 }
 
@@ -258,13 +247,13 @@ extern "C" int ftx_bn_train_fwd(const float *x, const float *residual, const flo
 // [2][c] of float64 column sums / sums of squares that pass leaves behind its partial rows.  One launch: x is read once.
 extern "C" int ftx_bn_train_fwd_totals(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean,
                                        float *running_var, float momentum, float eps, int64_t n, int32_t c, int32_t relu, float *y,
-                                       uint8_t *relu_mask, float *save_mean, float *save_invstd, const double *totals, void *stream) {
+                                       float *save_mean, float *save_invstd, const double *totals, void *stream) {
   int rc = bn_check("ftx_bn_train_fwd_totals", n, c);
   if (rc != FTX_OK) return rc;
   FTX_REQUIRE(n >= 1, "ftx_bn_train_fwd_totals: needs at least one row");
   FTX_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && totals, "ftx_bn_train_fwd_totals: null pointer");
   bn_apply_fwd_kernel<<<bn_apply_grid(n, c), 256, 0, (hipStream_t)stream>>>(x, residual, gamma, beta, totals, eps, momentum, running_mean,
-                                                                            running_var, save_mean, save_invstd, n, c, relu, y, relu_mask);
+                                                                            running_var, save_mean, save_invstd, n, c, relu, y);
   return check_launch("ftx_bn_train_fwd_totals");
 }
 
@@ -307,8 +296,7 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restri
                                                            const float *__restrict__ gamma, const float *__restrict__ mean,
                                                            const float *__restrict__ invstd, const double *__restrict__ sums, int64_t n, int c,
                                                            int relu, float *__restrict__ gx, float *__restrict__ gres,
-                                                           float *__restrict__ grad_gamma, float *__restrict__ grad_beta,
-                                                           const uint8_t *__restrict__ ymask) {
+                                                           float *__restrict__ grad_gamma, float *__restrict__ grad_beta) {
   const int c4 = c >> 2;
   const int RL = 256 / c4 > 0 ? 256 / c4 : 1;
   const int cg = threadIdx.x % c4, rl = threadIdx.x / c4;
@@ -334,12 +322,7 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restri
     const float4 x4 = *(const float4 *)&x[o];
     float dy[4] = {g4.x, g4.y, g4.z, g4.w};
     const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
-    if (relu && ymask) {
-      const unsigned m = ymask[r * c4 + cg];
-#pragma unroll
-      for (int v = 0; v < 4; ++v)
-        if (!((m >> v) & 1u)) dy[v] = 0.f;
-    } else if (relu) {
+    if (relu) {
       const float4 y4 = *(const float4 *)&y[o];
       const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
 #pragma unroll
@@ -364,15 +347,14 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restri
   if (r < n) one(r);
 }
 
-extern "C" int ftx_bn_train_bwd(const float *grad_y, const float *x, const float *y, const uint8_t *relu_mask, const float *gamma,
-                                const float *save_mean, const float *save_invstd, int64_t n, int32_t c, int32_t relu, float *grad_x,
-                                float *grad_residual, float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes,
-                                void *stream) {
+extern "C" int ftx_bn_train_bwd(const float *grad_y, const float *x, const float *y, const float *gamma, const float *save_mean,
+                                const float *save_invstd, int64_t n, int32_t c, int32_t relu, float *grad_x, float *grad_residual,
+                                float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream) {
   int rc = bn_check("ftx_bn_train_bwd", n, c);
   if (rc != FTX_OK) return rc;
   FTX_REQUIRE(n >= 1, "ftx_bn_train_bwd: needs at least one row");
   FTX_REQUIRE(grad_y && x && gamma && save_mean && save_invstd && grad_x && workspace, "ftx_bn_train_bwd: null pointer");
-  FTX_REQUIRE(!relu || y || relu_mask, "ftx_bn_train_bwd: relu needs the forward output y or the mask the forward wrote");
+  FTX_REQUIRE(!relu || y, "ftx_bn_train_bwd: relu needs the forward output y");
   FTX_REQUIRE(c <= 512, "ftx_bn_train_bwd: c > 512 unsupported");
   if (workspace_bytes < ftx_bn_workspace_bytes(n, c)) {
     set_error("ftx_bn_train_bwd: workspace %zu < required %zu", workspace_bytes, ftx_bn_workspace_bytes(n, c));
@@ -384,11 +366,9 @@ extern "C" int ftx_bn_train_bwd(const float *grad_y, const float *x, const float
   const int nb = bn_blocks(n);
   double *part = (double *)workspace;
   double *sums = part + (size_t)nb * 2 * c;   // written by the last block of the statistics pass
-  const uint8_t *mask = relu ? relu_mask : nullptr;
-  bn_partial_kernel<BwdOp><<<nb, 256, bn_partial_lds(c), st>>>(x, grad_y, (relu && !mask) ? y : nullptr, mask, save_mean, save_invstd, relu, n, c,
-                                                               part, sc);
+  bn_partial_kernel<BwdOp><<<nb, 256, bn_partial_lds(c), st>>>(x, grad_y, relu ? y : nullptr, save_mean, save_invstd, relu, n, c, part, sc);
   bn_apply_bwd_kernel<<<bn_apply_grid(n, c), 256, 0, st>>>(grad_y, x, y, gamma, save_mean, save_invstd, sums, n, c, relu, grad_x, grad_residual,
-                                                           grad_gamma, grad_beta, mask);
+                                                           grad_gamma, grad_beta);
   return check_launch("ftx_bn_train_bwd");
 }
 

@@ -580,22 +580,21 @@ class _BatchNormTrain(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = _empty((c,), F32, x)
         invstd = _empty((c,), F32, x)
-        mask = _relu_mask(n, c, x) if relu else None     # one byte per four outputs: what the backward reads instead of y
         ws_bytes = _ws_bytes("ftx_bn_workspace_bytes", n, c)
         ws = _scratch(ws_bytes, x)
         _log_launch("bn_fwd", dict(n=n, c=c, reads=2 + (residual is not None), writes=1), lambda: check(L.ftx_bn_train_fwd(
             ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps),
-            n, c, int(relu), ptr(y), ptr(mask), ptr(mean), ptr(invstd), ptr(ws), ws_bytes, stream()), "ftx_bn_train_fwd"))
-        ctx.save_for_backward(x, mask if (mask is not None or not relu) else y, gamma, mean, invstd)
+            n, c, int(relu), ptr(y), ptr(mean), ptr(invstd), ptr(ws), ws_bytes, stream()), "ftx_bn_train_fwd"))
+        ctx.save_for_backward(x, y, gamma, mean, invstd)
         ctx.relu = int(relu)
         ctx.has_res = residual is not None
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, mask, gamma, mean, invstd = ctx.saved_tensors
+        x, y, gamma, mean, invstd = ctx.saved_tensors
         gy = req(gy.contiguous(), F32, "bn grad", 2)
-        gx, gres, ggamma, gbeta = _bn_backward_launch(gy, x, mask, gamma, mean, invstd, ctx.relu, ctx.has_res)
+        gx, gres, ggamma, gbeta = _bn_backward_launch(gy, x, y, gamma, mean, invstd, ctx.relu, ctx.has_res)
         return gx, gres, ggamma, gbeta, None, None, None, None, None
 
 
@@ -624,21 +623,7 @@ class _BatchNormEval(torch.autograd.Function):
         return gx, (dy if ctx.has_res else None), None, None, None, None, None, None
 
 
-_BN_MASK = os.environ.get("FTX_BN_MASK", "1") != "0"      # A/B aid: 0 = the backward reads the forward output y for the ReLU mask
-
-
-def _relu_mask(n, c, like):
-    return torch.empty((int(n) * (int(c) // 4),), dtype=torch.uint8, device=like.device) if _BN_MASK else None
-
-
-def _mask_args(m):
-    """(y pointer, mask pointer) for ftx_bn_train_bwd from what the forward saved: the mask bytes, or (FTX_BN_MASK=0) the output y."""
-    if m is None:
-        return 0, 0
-    return (0, m.data_ptr()) if m.dtype == torch.uint8 else (m.data_ptr(), 0)
-
-
-def _bn_backward_launch(gy, x, mask, gamma, mean, invstd, relu, has_res):
+def _bn_backward_launch(gy, x, y, gamma, mean, invstd, relu, has_res):
     L = _lib.load()
     n, c = x.shape
     gx = torch.empty_like(x)
@@ -647,9 +632,9 @@ def _bn_backward_launch(gy, x, mask, gamma, mean, invstd, relu, has_res):
     gbeta = _empty((c,), F32, x)
     ws_bytes = _ws_bytes("ftx_bn_workspace_bytes", n, c)
     ws = _scratch(ws_bytes, x)
-    # two passes (statistics, apply), each reading gy and x (and the ReLU mask bytes: 1/16 of a row matrix); one or two row matrices written
-    _log_launch("bn_bwd", dict(n=n, c=c, reads=2 * (2 + (0.0625 if relu else 0)), writes=1 + (1 if has_res else 0)), lambda: check(L.ftx_bn_train_bwd(
-        ptr(gy), ptr(x), *_mask_args(mask), ptr(gamma), ptr(mean), ptr(invstd), n, c, int(relu), ptr(gx), ptr(gres), ptr(ggamma),
+    # two passes (statistics, apply), each reading gy and x (and y for the ReLU mask); one or two row matrices written
+    _log_launch("bn_bwd", dict(n=n, c=c, reads=2 * (2 + (1 if relu else 0)), writes=1 + (1 if has_res else 0)), lambda: check(L.ftx_bn_train_bwd(
+        ptr(gy), ptr(x), ptr(y), ptr(gamma), ptr(mean), ptr(invstd), n, c, int(relu), ptr(gx), ptr(gres), ptr(ggamma),
         ptr(gbeta), ptr(ws), ws_bytes, stream()), "ftx_bn_train_bwd"))
     return gx, gres, ggamma, gbeta
 
@@ -679,7 +664,6 @@ class _ConvBNTrain(torch.autograd.Function):
                 raise ValueError("conv_bn: BatchNorm parameter length != output channels")
         stats = _empty((2, co), F32, feats)              # row 0: batch mean, row 1: 1 / sqrt(var + eps)
         p_mean, p_invstd = stats.data_ptr(), stats.data_ptr() + 4 * co
-        mask = _relu_mask(n_out, co, feats) if relu else None
         st = stream()
         direct = (transposed and km.fine_bijective) or n_out == 0 or km.n_pairs == 0
         if direct:
@@ -689,7 +673,7 @@ class _ConvBNTrain(torch.autograd.Function):
             ws, = _carve(x, ws_bytes)
             _log_launch("bn_fwd", dict(n=n_out, c=co, reads=2 + (residual is not None), writes=1), lambda: check(L.ftx_bn_train_fwd(
                 ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps),
-                n_out, co, int(relu), ptr(y), ptr(mask), p_mean, p_invstd, ws, ws_bytes, st), "ftx_bn_train_fwd"))
+                n_out, co, int(relu), ptr(y), p_mean, p_invstd, ws, ws_bytes, st), "ftx_bn_train_fwd"))
         else:
             gather, pos = (km.pair_out, km.pos_t) if transposed else (km.pair_in, km.pos)
             x = _empty((n_out, co), F32, feats)
@@ -703,15 +687,15 @@ class _ConvBNTrain(torch.autograd.Function):
                 tmp, ptr(pos), n_out, co, kvol, ptr(x), part, nb, st), "ftx_spconv_reduce_stats"))
             _log_launch("bn_fwd", dict(n=n_out, c=co, reads=1 + (residual is not None), writes=1), lambda: check(L.ftx_bn_train_fwd_totals(
                 ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum),
-                float(eps), n_out, co, int(relu), ptr(y), ptr(mask), p_mean, p_invstd, part + 16 * nb * co, st), "ftx_bn_train_fwd_totals"))
-        ctx.save_for_backward(feats, kernel, x, mask if (mask is not None or not relu) else y, gamma, stats)
+                float(eps), n_out, co, int(relu), ptr(y), p_mean, p_invstd, part + 16 * nb * co, st), "ftx_bn_train_fwd_totals"))
+        ctx.save_for_backward(feats, kernel, x, y, gamma, stats)
         ctx.km, ctx.transposed, ctx.relu, ctx.has_res = km, transposed, int(relu), residual is not None
         return y
 
     @staticmethod
     def backward(ctx, gy):
         L = _lib.load()
-        feats, kernel, x, mask, gamma, stats = ctx.saved_tensors
+        feats, kernel, x, y, gamma, stats = ctx.saved_tensors
         km, transposed = ctx.km, ctx.transposed
         gy = req(gy.contiguous(), F32, "conv_bn grad", 2)
         n, co = x.shape
@@ -729,8 +713,8 @@ class _ConvBNTrain(torch.autograd.Function):
         tmp_bytes = 4 * km.n_pairs * ca if (need_feats and not direct) else 0
         bn_ws, gx, tmp, wg_ws = _carve(x, bn_ws_bytes, 4 * n * co, tmp_bytes, wg_bytes)
         # BatchNorm half: gx = d loss / d (convolution output) stays in the scratch buffer, it is consumed by the two calls below
-        _log_launch("bn_bwd", dict(n=n, c=co, reads=2 * (2 + (0.0625 if ctx.relu else 0)), writes=1 + (1 if ctx.has_res else 0)), lambda: check(L.ftx_bn_train_bwd(
-            ptr(gy), ptr(x), *_mask_args(mask), ptr(gamma), p_mean, p_invstd, n, co, ctx.relu, gx, ptr(gres), gparams.data_ptr(), gparams.data_ptr() + 4 * co,
+        _log_launch("bn_bwd", dict(n=n, c=co, reads=2 * (2 + (1 if ctx.relu else 0)), writes=1 + (1 if ctx.has_res else 0)), lambda: check(L.ftx_bn_train_bwd(
+            ptr(gy), ptr(x), ptr(y), ptr(gamma), p_mean, p_invstd, n, co, ctx.relu, gx, ptr(gres), gparams.data_ptr(), gparams.data_ptr() + 4 * co,
             bn_ws, bn_ws_bytes, st), "ftx_bn_train_bwd"))
         g_feats = g_kernel = None
         meta = dict(pairs=km.n_pairs, n_out=n_feats, ca=co, co=ca, kvol=kvol)

@@ -218,20 +218,18 @@ int ftx_spconv_pairs_wgrad(const float *A, int64_t rows_a, const int32_t *idx_a,
  * normalisation, unbiased for running_var, momentum as torch), then
  * y = relu?( (x-mean)*invstd*gamma + beta (+ residual) ).
  * save_mean / save_invstd (c) are outputs for the backward.
- * running_mean / running_var may be NULL (no update).  residual may be NULL.
- * relu_mask (n * c/4 bytes, may be NULL): with relu != 0 the forward also writes one byte per four outputs, bit v set where output v
- * is > 0; the backward takes it INSTEAD of reading y (1/16 of the bytes in both of its passes). */
+ * running_mean / running_var may be NULL (no update).  residual may be NULL. */
 size_t ftx_bn_workspace_bytes(int64_t n, int32_t c);
-int ftx_bn_train_fwd(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean, float *running_var, float momentum, float eps, int64_t n, int32_t c, int32_t relu, float *y, uint8_t *relu_mask, float *save_mean, float *save_invstd, void *workspace, size_t workspace_bytes, void *stream);
+int ftx_bn_train_fwd(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean, float *running_var, float momentum, float eps, int64_t n, int32_t c, int32_t relu, float *y, float *save_mean, float *save_invstd, void *workspace, size_t workspace_bytes, void *stream);
 /* Training-mode BatchNorm forward from the column totals (2, c) float64 that ftx_spconv_reduce_stats left: one launch that
  * derives mean / invstd, updates the running statistics, stores save_mean / save_invstd and applies. */
-int ftx_bn_train_fwd_totals(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean, float *running_var, float momentum, float eps, int64_t n, int32_t c, int32_t relu, float *y, uint8_t *relu_mask, float *save_mean, float *save_invstd, const double *totals, void *stream);
+int ftx_bn_train_fwd_totals(const float *x, const float *residual, const float *gamma, const float *beta, float *running_mean, float *running_var, float momentum, float eps, int64_t n, int32_t c, int32_t relu, float *y, float *save_mean, float *save_invstd, const double *totals, void *stream);
 
 /* Eval forward with running statistics. */
 int ftx_bn_eval_fwd(const float *x, const float *residual, const float *gamma, const float *beta, const float *running_mean, const float *running_var, float eps, int64_t n, int32_t c, int32_t relu, float *y, void *stream);
-/* Training backward.  The ReLU mask when relu != 0: relu_mask as written by the forward, or (relu_mask NULL) the forward output y.
+/* Training backward.  y is the forward output (needed for the ReLU mask when relu!=0).
  * grad_x (n,c), grad_residual (n,c, may be NULL), grad_gamma (c), grad_beta (c). */
-int ftx_bn_train_bwd(const float *grad_y, const float *x, const float *y, const uint8_t *relu_mask, const float *gamma, const float *save_mean, const float *save_invstd, int64_t n, int32_t c, int32_t relu, float *grad_x, float *grad_residual, float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream);
+int ftx_bn_train_bwd(const float *grad_y, const float *x, const float *y, const float *gamma, const float *save_mean, const float *save_invstd, int64_t n, int32_t c, int32_t relu, float *grad_x, float *grad_residual, float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- optimizer step: torch.optim.Adam (L2 weight decay, no amsgrad) over every parameter tensor in one launch ----
  * (common/solver/build.py:7-20 builds the optimizer, modules/SemanticTrainer.py:141-209 steps it once per batch.)
