@@ -894,6 +894,21 @@ def test_round2_entry_points_edge_cases(env):
     np.testing.assert_allclose(part[:nb].sum(0)[1].cpu().numpy(), (tmp[0].double() ** 2).cpu().numpy(), rtol=1e-15)
     assert torch.equal(part[nb], part[:nb].sum(0))                               # totals by the last block to finish
     assert L.ftx_spconv_reduce_stats(tmp.data_ptr(), pos.data_ptr(), 1, 8, 27, o1.data_ptr(), part.data_ptr(), nb + 1, spf.stream()) != 0
+    # one-launch Adam: bad hyper-parameters and null tables are refused before anything is launched; zero chunks is a no-op
+    assert L.ftx_adam_step(0, 0, 0, 0, 0.9, 0.999, 1e-8, 0.0, spf.stream()) == 0
+    assert L.ftx_adam_step(0, 0, 0, 1, 0.9, 0.999, 1e-8, 0.0, spf.stream()) != 0 and b"null" in L.ftx_last_error()
+    one = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    assert L.ftx_adam_step(one.data_ptr(), one.data_ptr(), one.data_ptr(), 1, 1.0, 0.999, 1e-8, 0.0, spf.stream()) != 0
+    assert b"hyper-parameter" in L.ftx_last_error()
+    # fused add + LayerNorm: a bias for y without y, and a too-small backward workspace
+    v = torch.zeros(4, 256, device="cuda"); w1 = torch.ones(256, device="cuda"); st = torch.zeros(2, 4, device="cuda")
+    assert L.ftx_add_layernorm_fwd(v.data_ptr(), 0, w1.data_ptr(), w1.data_ptr(), w1.data_ptr(), 1e-6, 4, 256, 0, v.data_ptr(), st.data_ptr(),
+                                   st.data_ptr() + 16, spf.stream()) != 0
+    assert b"y_bias without y" in L.ftx_last_error()
+    gp = torch.zeros(3, 256, device="cuda")
+    assert L.ftx_add_layernorm_bwd(v.data_ptr(), 0, v.data_ptr(), w1.data_ptr(), st.data_ptr(), st.data_ptr() + 16, 4, 256, 0, v.data_ptr(), gp.data_ptr(),
+                                   one.data_ptr(), 8, spf.stream()) != 0
+    assert b"workspace" in L.ftx_last_error()
     # the fused loss refuses an unknown mix
     with pytest.raises(ValueError):
         spf.fusion_loss({}, torch.zeros(1), None, 0.1, False, mix="other")
