@@ -317,6 +317,43 @@ def test_index_built_ahead_is_bit_identical_to_index_built_in_the_forward():
         assert torch.equal(pa[n], pb[n]), n
 
 
+def test_resume_from_state_dicts_continues_bit_identically():
+    """model.state_dict() + optimizer.state_dict() after two steps, loaded into a fresh model / TrainStep: the third step lands on the same
+    bits as the run that never stopped (BatchNorm buffers, the one-launch Adam's moments and step counters, graphed trunk and all)."""
+    import copy
+    from fusiontransformer_amd.data.synth import make_batch
+    from fusiontransformer_amd.models.build import build_model
+    from fusiontransformer_amd.trainer import TrainStep
+    cfg, _, model, _ = _pair("middle", seed=8)
+    model.train()
+    step = TrainStep(cfg, model)
+    pins = [product_inputs(make_batch([11, 12], max_points=3000)), product_inputs(make_batch([13], max_points=2500))]
+    for i in range(2):
+        torch.manual_seed(i)
+        step(pins[i % 2])
+    torch.cuda.synchronize()
+    msd = copy.deepcopy(model.state_dict())
+    osd = copy.deepcopy(step.optimizer.state_dict())
+    torch.manual_seed(2)
+    step(pins[0])
+    torch.cuda.synchronize()
+    want = {n: p.detach().clone() for n, p in model.named_parameters()}
+    want_buf = {n: b.detach().clone() for n, b in model.named_buffers()}
+
+    model2, _, _ = build_model(cfg)
+    model2 = model2.cuda().train()
+    model2.load_state_dict(msd)
+    step2 = TrainStep(cfg, model2)
+    step2.optimizer.load_state_dict(osd)
+    torch.manual_seed(2)
+    step2(pins[0])
+    torch.cuda.synchronize()
+    for n, p in model2.named_parameters():
+        assert torch.equal(p, want[n]), n
+    for n, b in model2.named_buffers():
+        assert torch.equal(b, want_buf[n]), n
+
+
 def test_bf16_forward_mode_stays_close_to_the_fp32_oracle():
     """BASELINE configs[4] ("bf16 forward"): ViT GEMM operands in bf16.  The reference has no such mode (it is fp32 end
     to end), so the bar is the fp32 oracle with a looser tolerance, stated here: per-point logits within 3e-2 (measured
