@@ -97,7 +97,7 @@ def spconv_roofline(log, workload=None):
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             if pmc["workload"] == workload:
                 traffic = int(pmc["fetch_corrected_bytes_per_step"] + pmc["write_bytes_per_step"])
-                traffic_note = ("bytes per step over the same kernels: FETCH_SIZE x2 (gfx950 correction, upper bound for 16-B gathers) + WRITE_SIZE, "
+                traffic_note = ("bytes per step over the same kernels: FETCH_SIZE x2 (gfx950 correction; checked on this library's row gathers: tools/probes/fetch_calibration.py) + WRITE_SIZE, "
                                 "rocprofv3 --pmc in separate passes, profiles/" + name)
                 break
         except (OSError, KeyError, ValueError):

@@ -23,8 +23,8 @@ fetch, write, steps = per_kernel(sys.argv[1], "FETCH_SIZE", float(sys.argv[3])),
 out = {
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-tune-gemm; "
               "per training step (all %d steps of the run incl. warm-up averaged), summed over the sparse-conv kernels" % int(steps),
-    "units": "counter values are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads; uncalibrated for the "
-             "16-B gathers used here, so the corrected figure is an upper bound)",
+    "units": "counter values are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads; the same factor "
+             "was measured on this library's row gathers, 128-B and 512-B rows: tools/probes/fetch_calibration.py, profiles/r02_fetch_calibration.txt)",
     "fetch_raw_bytes_per_step": sum(v[1] for v in fetch.values()),
     "fetch_corrected_bytes_per_step": 2 * sum(v[1] for v in fetch.values()),
     "write_bytes_per_step": sum(v[1] for v in write.values()),
