@@ -11,6 +11,7 @@ torch's hipBLASLt GEMMs; softmax(QK^T/8)V runs in libftx's fused attention
 kernel when `attn_impl == "ftx"`, otherwise as the three explicit ops timm uses."""
 from __future__ import annotations
 
+import os
 from functools import partial
 from typing import Dict
 
@@ -302,7 +303,7 @@ class Image2DTransformer(nn.Module):
 
     # ---- HIP-graph execution of the trunk ------------------------------------------------------------------
     graph_taps = None   # sorted block indices whose outputs the caller uses; None: eager execution
-    graph_segment_blocks = 3
+    graph_segment_blocks = int(os.environ.get("FTX_GRAPH_SEGMENT_BLOCKS", "3"))   # blocks per captured segment (a tap always ends one)
 
     def _graph_key(self, x):
         """Everything a captured graph bakes in: input shape / dtype / requires_grad, the tap set and segment length, the
