@@ -188,8 +188,8 @@ def cpu_baseline(cfg, np_batch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="frames per GPU per step")
     ap.add_argument("--cycle", type=int, default=2, help="distinct resident batches the steps alternate between (>= 2: nothing per-batch can be cached across steps)")
     ap.add_argument("--shape", default="kitti", choices=["kitti", "nuscenes"])

@@ -26,6 +26,11 @@ constexpr float LN2 = 0.6931471805599453f;
 
 __device__ inline int acc_row(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
 
+// 2^x as the bare v_exp_f32: every argument in these kernels is <= 0 up to rounding (a score minus its row maximum / log-sum-exp)
+// or -inf (a masked key), so exp2f()'s range fix-ups -- a compare, two selects and an ldexp per call, 5 of the 6 instructions --
+// have nothing to fix; results below 2^-126 flush to zero, which is what a softmax weight of that size is worth.
+__device__ inline float exp2_raw(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // qkv (b, t, 3, nh, 64): row of tensor `which` (0 q, 1 k, 2 v) for token t, head hd
 __device__ inline const float *qkv_row(const float *qkv, int b, int t, int which, int hd, int T, int nh) {
   return qkv + ((((int64_t)b * T + t) * 3 + which) * nh + hd) * HD;
@@ -175,6 +180,8 @@ __global__ __launch_bounds__(64 * QW * SPLIT) void attn_fwd_kernel(const float *
 
   float qf[32];
   load_frag(qkv_row(qkv, b, qv ? q : 0, 0, hd, T, nh), h, qv, qf);
+#pragma unroll
+  for (int i = 0; i < 32; ++i) qf[i] *= sl2;   // scale * log2(e) folded into Q once: S^T comes out of the MFMAs in the exp2 domain
 
   f32x16 o0, o1;
 #pragma unroll
@@ -196,37 +203,39 @@ __global__ __launch_bounds__(64 * QW * SPLIT) void attn_fwd_kernel(const float *
       tile_prefetch<NT>(qkv, b, hd, 2, (kt + SPLIT) * 32, T, nh, tid, rv);
     }
     if (kt < ntiles) {
-      // S^T[key][q]: rows = keys of this tile, column = this lane's query
+      // S^T[key][q] * scale * log2(e): rows = keys of this tile, column = this lane's query
       f32x16 st;
 #pragma unroll
       for (int g = 0; g < 16; ++g) st[g] = 0.f;
       mfma_lds_x_frag(Ks, l31, h, qf, st);
-      float mx = -INFINITY;
+      if (kt == ntiles - 1) {   // only the last tile has keys past T (wave-uniform branch)
 #pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        float sv = st[g] * sl2;
-        if (kt * 32 + acc_row(g, h) >= T) sv = -INFINITY;
-        st[g] = sv;
-        mx = fmaxf(mx, sv);
+        for (int g = 0; g < 16; ++g)
+          if (kt * 32 + acc_row(g, h) >= T) st[g] = -INFINITY;
       }
+      float mx = fmaxf(fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3])), fmaxf(fmaxf(st[4], st[5]), fmaxf(st[6], st[7])));
+      mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(st[8], st[9]), fmaxf(st[10], st[11])), fmaxf(fmaxf(st[12], st[13]), fmaxf(st[14], st[15]))));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));     // the other 16 keys of the tile live in the partner half
       const float m_new = fmaxf(m, mx);
-      const float alpha = exp2f(m - m_new);
       float rs = 0.f;
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
-        float p = exp2f(st[g] - m_new);
+        float p = exp2_raw(st[g] - m_new);
         st[g] = p;
         rs += p;
       }
       rs += __shfl_xor(rs, 32, 64);
-      l = l * alpha + rs;
-      m = m_new;
+      if (__any(m_new != m)) {   // the running maximum moved for some query of this wave: rescale (a factor of exactly 1 is skipped)
+        const float alpha = exp2_raw(m - m_new);
+        l *= alpha;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        o0[g] *= alpha;
-        o1[g] *= alpha;
+        for (int g = 0; g < 16; ++g) {
+          o0[g] *= alpha;
+          o1[g] *= alpha;
+        }
       }
+      l += rs;
+      m = m_new;
       // O^T[dv][q] += sum_key V[key][dv] * P^T[key][q]
       mfma_ldsT_x_acc(Vs, 0, l31, h, st, o0);
       mfma_ldsT_x_acc(Vs, 32, l31, h, st, o1);
@@ -316,6 +325,8 @@ __global__ __launch_bounds__(64 * QW * SPLIT) void attn_bwd_kv_kernel(const floa
   float kf[32], vf[32];
   load_frag(qkv_row(qkv, b, kv ? key : 0, 1, hd, T, nh), h, kv, kf);
   load_frag(qkv_row(qkv, b, kv ? key : 0, 2, hd, T, nh), h, kv, vf);
+#pragma unroll
+  for (int i = 0; i < 32; ++i) kf[i] *= sl2;   // only S uses this fragment: S comes out of the MFMAs in the exp2 domain
 
   f32x16 acc[4];   // dV^T tile 0/1, dK^T tile 0/1
 #pragma unroll
@@ -349,13 +360,19 @@ __global__ __launch_bounds__(64 * QW * SPLIT) void attn_bwd_kv_kernel(const floa
       for (int g = 0; g < 16; ++g) s[g] = dp[g] = 0.f;
       mfma_lds_x_frag(Qs, l31, h, kf, s);
       mfma_lds_x_frag(Gs, l31, h, vf, dp);
+      // P = exp2(S - lse), dS = P (dP - delta) scale.  A key lane past T holds zero K / V fragments: its column is finite garbage
+      // that is never stored; query rows past T exist in the last tile only (wave-uniform branch).
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
-        int r = acc_row(g, h);
-        bool ok = kv && (qt * 32 + r < T);
-        float p = ok ? exp2f(s[g] * sl2 - s_lse[r]) : 0.f;
+        const int r = acc_row(g, h);
+        const float p = exp2_raw(s[g] - s_lse[r]);
         s[g] = p;                                            // P
         dp[g] = p * (dp[g] - s_delta[r]) * scale;             // dS
+      }
+      if (qt == ntiles - 1) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g)
+          if (qt * 32 + acc_row(g, h) >= T) s[g] = dp[g] = 0.f;
       }
       // dV^T[dv][key] += sum_q dO[q][dv] P[q][key];  dK^T[d][key] += sum_q Q[q][d] dS[q][key]
       mfma_ldsT_x_acc(Gs, 0, l31, h, s, acc[0]);
@@ -397,6 +414,8 @@ __global__ __launch_bounds__(64 * QW * SPLIT) void attn_bwd_q_kernel(const float
 
   float qf[32], gf[32];
   load_frag(qkv_row(qkv, b, qv ? q : 0, 0, hd, T, nh), h, qv, qf);
+#pragma unroll
+  for (int i = 0; i < 32; ++i) qf[i] *= sl2;   // only S^T uses this fragment
   load_frag(go + (((int64_t)b * T + (qv ? q : 0)) * nh + hd) * HD, h, qv, gf);
   const float my_lse = qv ? lse[((int64_t)b * nh + hd) * T + q] * LOG2E : 0.f;
   const float my_delta = qv ? delta[((int64_t)b * nh + hd) * T + q] : 0.f;
@@ -428,9 +447,13 @@ __global__ __launch_bounds__(64 * QW * SPLIT) void attn_bwd_q_kernel(const float
       mfma_lds_x_frag(Vs, l31, h, gf, dpt);
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
-        bool ok = qv && (kt * 32 + acc_row(g, h) < T);
-        float p = ok ? exp2f(st[g] * sl2 - my_lse) : 0.f;
+        const float p = exp2_raw(st[g] - my_lse);
         dpt[g] = p * (dpt[g] - my_delta) * scale;   // dS^T
+      }
+      if (kt == ntiles - 1) {   // key rows past T: only in the last tile (their K rows are zero, so P would be exp2(-lse), not 0)
+#pragma unroll
+        for (int g = 0; g < 16; ++g)
+          if (kt * 32 + acc_row(g, h) >= T) dpt[g] = 0.f;
       }
       // dQ^T[d][q] += sum_key K[key][d] dS^T[key][q]
       mfma_ldsT_x_acc(Ks, 0, l31, h, dpt, acc[0]);
