@@ -57,7 +57,7 @@ def spconv_roofline(log, workload=None):
     the kernel weights 4*kvol*ca*co read once per convolution.  A convolution is two launches
     (pair gather-GEMM, ordered reduce), or one (weight gradient; bijective maps, whose GEMM epilogue writes the output
     itself); the bytes are attributed to the GEMM / wgrad launch, the reduce launch adds time only."""
-    tot_bytes = tot_ms = tot_flops = 0.0
+    tot_bytes = tot_ms = tot_flops = tot_roof_ms = 0.0
     per_kind = {}
     bn = {"launches": 0, "ms": 0.0, "bytes": 0.0}
     attn = {"launches": 0, "ms": 0.0, "flops": 0.0}
@@ -82,6 +82,8 @@ def spconv_roofline(log, workload=None):
         tot_bytes += nbytes
         tot_ms += ms
         tot_flops += flops
+        # the roof that binds THIS launch: its algorithmic bytes at the HBM peak or its flops at the exact-fp32 MFMA peak, whichever is longer
+        tot_roof_ms += 1e3 * max(nbytes / (HBM_PEAK_GBS * 1e9), flops / (MFMA_F32_PEAK_TFLOPS * 1e12))
         k = per_kind.setdefault(kind, [0, 0.0, 0.0, 0.0])
         k[0] += 1
         k[1] += ms
@@ -92,7 +94,7 @@ def spconv_roofline(log, workload=None):
     achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
     n_conv = sum(v[0] for k, v in per_kind.items() if k != "spconv_reduce")
     traffic, traffic_note = None, None
-    for name in ("r02_pmc_hbm_spconv.json", "r01_pmc_hbm_spconv.json"):
+    for name in ("r03_pmc_hbm_spconv.json", "r02_pmc_hbm_spconv.json", "r01_pmc_hbm_spconv.json"):
         try:  # HBM bytes of these kernels from the PMC passes committed under profiles/ (same workload)
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             if pmc["workload"] == workload:
@@ -119,7 +121,10 @@ def spconv_roofline(log, workload=None):
     return {
         "bound": "hbm", "kernel": "pairs_gemm_kernel + spconv_reduce(_stats)_kernel + pairs_wgrad_kernel + wgrad_reduce_kernel (sparse conv fwd / dgrad / wgrad)",
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-        "traffic": traffic, "traffic_note": traffic_note,
+        "binding_frac": round(tot_roof_ms / tot_ms, 4),
+        "binding_frac_rule": "sum over the convolutions of max(algorithmic bytes / HBM peak, 2*pairs*ca*co flop / exact-fp32 MFMA peak) / sum of the HIP-event "
+                             "time of all sparse-conv launches (reduce passes add time only): the fraction of each launch's own binding roof",
+        "traffic": traffic, "traffic_from_committed_profile": traffic is not None, "traffic_note": traffic_note,
         "launches": n_sp, "convolutions": n_conv, "avg_conv_us": round(1e3 * tot_ms / max(n_conv, 1), 2),
         "algorithmic_bytes_per_step": int(tot_bytes), "useful_tflops": round(tot_flops / (tot_ms * 1e-3) / 1e12, 3),
         "mfma_f32_peak_tflops": MFMA_F32_PEAK_TFLOPS,
@@ -146,6 +151,16 @@ def host_cores():
     except (OSError, ValueError):
         pass
     return max(1, min(n, 32))
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def log(msg):
@@ -181,8 +196,88 @@ def cpu_baseline(cfg, np_batch):
         one()
         times.append(time.perf_counter() - t)
         log("cpu_baseline: pass %.1f s" % times[-1])
-    return {"value": round(1.0 / float(np.median(times)), 4), "unit": "frames/s", "cores": nthreads, "kind": "port",
+    return {"value": round(1.0 / float(np.median(times)), 4), "unit": "frames/s", "cores": nthreads, "cpu_model": cpu_model(), "kind": "port",
             "sample": "1 synthetic SemanticKITTI frame (%d points), fwd+bwd, batch 1, 1 warm-up + %d timed passes (median), torch CPU fp32 (CPU restatement of the reference, oracle/ft_oracle.py)" % (b["coords"].shape[0], len(times))}
+
+
+def launch_command(gpus, argv, port=None):
+    """The command `python bench.py --gpus N` turns itself into when it was NOT started by a launcher: one fresh process per GPU
+    under torch.distributed.run (the driver's own N > 1 command line; the reference's is `torchpack dist-run -np N`, torchpack_run.sh:3)."""
+    if port is None:
+        import socket
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % gpus, "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(gpus, argv):
+    """Parent of a self-launched N > 1 run: it never touches the GPU (importing torch does not initialise HIP), starts the ranks as
+    CHILD processes -- no exec of this process -- and exits with their code; rank 0's JSON line reaches stdout through inheritance."""
+    import subprocess
+    cmd = launch_command(gpus, argv)
+    log("WORLD_SIZE is not set: starting %d ranks: %s" % (gpus, " ".join(cmd)))
+    return subprocess.run(cmd).returncode
+
+
+def selfcheck(cfg, model, step, data, device, bf16, compare_grads):
+    """Evidence that the timed configuration computes the right thing: one more step on `data` exactly as the timed steps ran it
+    (HIP-graph trunk, two streams), then the SAME step from the same pre-step parameters on a twin model with the eager trunk
+    and both branches issued serially on one stream.  Deterministic kernels => the two must agree to the last bit; a kernel
+    skipped or fed a stale buffer inside a replayed graph shows up here instead of as a better number."""
+    from fusiontransformer_amd.models.build import build_model
+    from fusiontransformer_amd.trainer import TrainStep
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    lb = getattr(model, "lidar_backbone", None)
+    torch.manual_seed(4321)      # dropout
+    preds = step(data)
+    torch.cuda.synchronize()
+    logits = {k: v.detach().clone() for k, v in preds.items()}
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    losses = (float(step.last["loss_2d"].item()), float(step.last["loss_3d"].item()))
+    twin, _, _ = build_model(cfg)
+    twin.load_state_dict(state)
+    twin = twin.to(device).train()
+    twin.image_backbone.backbone.graph_taps = None
+    twin.overlap_branches = False
+    if bf16:
+        twin.image_backbone.backbone.set_bf16(True)
+    step_t = TrainStep(cfg, twin, loss_mix=step.loss_mix)
+    torch.manual_seed(4321)
+    preds_t = step_t(data)
+    torch.cuda.synchronize()
+    dlogit = max(float((logits[k] - preds_t[k].detach()).abs().max().item()) for k in logits)
+    out = {"what": "step K+1 as timed (graphed trunk, 2 streams) against an eager-trunk, one-stream twin from the same pre-step parameters",
+           "max_abs_dlogit": dlogit, "loss_2d": losses[0], "loss_3d": losses[1],
+           "twin_loss_2d": float(step_t.last["loss_2d"].item()), "twin_loss_3d": float(step_t.last["loss_3d"].item()),
+           "finite": bool(all(torch.isfinite(v).all().item() for v in logits.values()))}
+    if compare_grads:
+        worst, worst_name, n_cmp = 0.0, None, 0
+        for n, p in twin.named_parameters():
+            if p.grad is None:
+                continue
+            g = grads.get(n)
+            if g is None:
+                worst, worst_name = float("inf"), n
+                continue
+            den = float(p.grad.abs().max().item())
+            d = float((g - p.grad).abs().max().item())
+            d = d / den if den > 0 else d
+            if d > worst:
+                worst, worst_name = d, n
+            n_cmp += 1
+        out["max_rel_dgrad"] = worst
+        out["max_rel_dgrad_parameter"] = worst_name
+        out["gradients_compared"] = n_cmp
+    else:
+        out["max_rel_dgrad"] = None
+        out["gradients_compared"] = "no: p.grad holds the average over ranks"
+    out["bit_identical"] = bool(dlogit == 0.0 and (not compare_grads or out["max_rel_dgrad"] == 0.0))
+    del twin, step_t
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -209,7 +304,15 @@ def main():
                     help="build the coordinate structures of batch i+1 during step i (TrainStep(next_batch=...)) instead of inside its own forward; "
                          "measured slower on MI355X (batch 4: 128.8 against 139.7 frames/s), off by default")
     ap.add_argument("--no-tune-gemm", dest="tune_gemm", action="store_false", help="skip TunableOp selection of the library GEMM kernels")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="N = 1 only: create a one-rank RCCL communicator and run the gradient exchange of the N > 1 path (bucketed async all-reduces "
+                         "issued from the autograd hooks) inside every step; the result is the identity, the code path is the multi-GPU one")
+    ap.add_argument("--no-selfcheck", action="store_true", help="skip the graphed-vs-eager bit-identity check after the timed region")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (the reference's counterpart is torchpack_run.sh:3)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     from fusiontransformer_amd import functional as spf
     from fusiontransformer_amd.config import fusion_cfg
@@ -219,7 +322,8 @@ def main():
     from fusiontransformer_amd.trainer import TrainStep
 
     # FTX_DIST_BACKEND=gloo FTX_FORCE_DEVICE=0 rehearses the N>1 path with several ranks on ONE GPU
-    rank, world, local_rank = init_process_group(os.environ.get("FTX_DIST_BACKEND"))
+    force_coll = args.force_collectives or os.environ.get("FTX_FORCE_COLLECTIVES") == "1"
+    rank, world, local_rank = init_process_group(os.environ.get("FTX_DIST_BACKEND"), force=force_coll)
     if os.environ.get("FTX_FORCE_DEVICE") is not None:
         local_rank = int(os.environ["FTX_FORCE_DEVICE"])
     if world != args.gpus:
@@ -244,7 +348,7 @@ def main():
     model = model.to(device).train()
     if args.bf16_forward:
         model.image_backbone.backbone.set_bf16(True)
-    reducer = GradReducer(model) if world > 1 else None
+    reducer = GradReducer(model, force_collectives=force_coll) if (world > 1 or force_coll) else None
     step = TrainStep(cfg, model, metrics=(m2d, m3d), grad_reducer=reducer)
     batches = [build_inputs(cfg, args.batch, args.shape, rank, device, cycle=c) for c in range(max(1, args.cycle))]
     np_batch = batches[0][0]
@@ -270,6 +374,7 @@ def main():
     model.overlap_branches = not args.serial_branches
     t0 = time.perf_counter()
     launch_log = None
+    loss_first = loss_last = None
     for i in range(args.steps):
         if rank == 0 and i == args.steps - 1:
             # HIP events around every sparse-conv launch of the last timed step.  That one step issues
@@ -279,6 +384,9 @@ def main():
             model.overlap_branches = False
         j = args.warmup + i            # continue the warm-up's alternation: the batch of step j was prepared by step j - 1
         step(datas[j % len(datas)], nxt(datas, j))
+        if i == 0:
+            loss_first = step.last          # device tensors: read after the timed region
+        loss_last = step.last
     spf.LAUNCH_LOG = None
     model.overlap_branches = not args.serial_branches
     barrier()
@@ -287,6 +395,17 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    allreduce_ms = None
+    if reducer is not None:
+        allreduce_ms = reducer.allreduce_ms(3)    # collective: every rank takes part; gradients are overwritten (next step zeroes them)
+        barrier()
+    check = None
+    if not args.no_selfcheck:
+        # every rank runs it (the step contains collectives when N > 1); rank 0 reports
+        j = args.warmup + args.steps
+        check = selfcheck(cfg, model, step, datas[j % len(datas)], device, args.bf16_forward, compare_grads=(world == 1))
+        barrier()
 
     if rank == 0:
         log("%.1f ms/step" % (1e3 * elapsed / args.steps))
@@ -310,6 +429,20 @@ def main():
             "frames_per_sec_per_gpu": round(frames / elapsed / world, 3),
             "roofline": roof,
         }
+        trunk = getattr(getattr(model, "image_backbone", None), "backbone", None)
+        out["selfcheck"] = check
+        out["allreduce_ms_per_step_standalone"] = None if allreduce_ms is None else round(allreduce_ms, 3)
+        out["trunk_graphs"] = trunk.graph_state() if hasattr(trunk, "graph_state") else "n/a"
+        if loss_first is not None:
+            out["losses"] = {"first_timed_step": {k: round(float(v.item()), 6) for k, v in loss_first.items()},
+                             "last_timed_step": {k: round(float(v.item()), 6) for k, v in loss_last.items()},
+                             "note": "rank 0; additive mix CE + 0.1 KL (SemanticTrainer.py:158-178); random-init weights, Adam lr 1e-4"}
+        import torch.distributed as _d
+        out["rccl_ranks"] = (world if (_d.is_initialized() and _d.get_backend() == "nccl") else 0)
+        out["multi_gpu"] = ("measured: %d ranks over RCCL" % world) if (world > 1 and out["rccl_ranks"] > 1) else "unmeasured in this run (one GPU)"
+        out["collectives"] = ("none (single process, no process group)" if reducer is None else
+                              "%s backend, %d rank(s), %d flat buckets of <= 64 MB, async all-reduce from the autograd hooks%s"
+                              % (_d.get_backend(), world, len(reducer.buckets), " (forced at world size 1)" if world == 1 else ""))
         if roof is not None and args.attn == "ftx" and not args.no_attention_roofline:
             # The ViT trunk replays as HIP graphs, whose kernels cannot be bracketed by events from the host; the attention kernels are
             # timed here, standalone, at the workload's shape (same launches as inside the graphs), after the timed region.

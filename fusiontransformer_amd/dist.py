@@ -27,16 +27,32 @@ import torch
 import torch.distributed as dist
 
 
-def init_process_group(backend=None):
-    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the env (torchrun contract)."""
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def init_process_group(backend=None, force=False):
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the env (torchrun contract).
+
+    `force`: create the process group even at world size 1 (a one-rank RCCL communicator), so that the collective path of
+    GradReducer(force_collectives=True) -- communicator, `async_op` all-reduces issued from the autograd hooks, `work.wait()` --
+    runs on a single GPU exactly as it does on eight."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
         if backend == "nccl":
             torch.cuda.set_device(int(os.environ.get("FTX_FORCE_DEVICE", local_rank)))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
@@ -52,16 +68,21 @@ class _Bucket:
 class GradReducer:
     """Bucketed, overlapped gradient all-reduce (average) for `model`'s trainable parameters."""
 
-    def __init__(self, model, bucket_mb: float = 64.0, process_group=None, broadcast_params=True):
+    def __init__(self, model, bucket_mb: float = 64.0, process_group=None, broadcast_params=True, force_collectives=False):
+        """force_collectives: issue the broadcasts and all-reduces even at world size 1 (needs an initialised process group,
+        init_process_group(force=True)); the result is the identity, the code path is the N > 1 one."""
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if force_collectives and not dist.is_initialized():
+            raise RuntimeError("GradReducer(force_collectives=True) needs an initialised process group (init_process_group(force=True))")
+        self.active = self.world > 1 or bool(force_collectives)     # collectives are issued
         self.bucket_bytes = int(bucket_mb * 1024 * 1024)
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.step_idx = 0
         self.ready_order = []
         self._rebuilt = False
         self._record = False
-        if self.world > 1 and broadcast_params:
+        if self.active and broadcast_params:
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=0, group=self.pg)
         self._build(list(reversed(self.params)))
@@ -109,7 +130,7 @@ class GradReducer:
         """Every rank must cut the SAME buckets (collectives are matched by issue order), but the gradient-ready order a rank
         observed in step 0 depends on how its two branch streams and its autograd thread interleaved: rank 0's order is
         broadcast and adopted by all (one small int64 broadcast, once per job)."""
-        if self.world <= 1:
+        if not self.active:
             return order
         index = {p: i for i, p in enumerate(self.params)}
         ids = torch.tensor([index[p] for p in order], dtype=torch.int64)
@@ -138,14 +159,15 @@ class GradReducer:
 
     def _launch(self, b):
         b.launched = True
-        if self.world > 1:
+        if self.active:
             if b.flat.is_cuda:
                 # the model runs its two branches on two HIP streams, so a bucket's gradients may have
                 # been accumulated on different streams: order the reduction after every one of them
                 cur = torch.cuda.current_stream()
                 for ev in b.events:
                     cur.wait_event(ev)
-            b.flat.div_(self.world)
+            if self.world > 1:
+                b.flat.div_(self.world)
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     def _launch_ready_prefix(self):
@@ -158,7 +180,7 @@ class GradReducer:
             self.ready_order.append(p)
         b = self.buckets[self.bucket_of[p]]
         b.pending -= 1
-        if p.is_cuda and self.world > 1:
+        if p.is_cuda and self.active:
             ev = torch.cuda.Event()
             ev.record()          # on the stream that just accumulated this gradient
             b.events.append(ev)
@@ -175,3 +197,25 @@ class GradReducer:
                 b.work.wait()
                 b.work = None
         self.step_idx += 1
+
+    def allreduce_ms(self, reps: int = 3):
+        """Standalone cost of one step's gradient exchange: every bucket all-reduced back to back with nothing else on the
+        device, HIP-event time per repetition.  Overwrites the gradients (call it outside a step); None when no collective
+        would be issued."""
+        if not self.active:
+            return None
+        flat = [b.flat for b in self.buckets]
+        if not flat or not flat[0].is_cuda:
+            return None
+        for t in flat:                      # one untimed pass: communicator / channel set-up
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True) for t in flat]
+            for w in works:
+                w.wait()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps

@@ -46,6 +46,13 @@ def _ws_bytes(fn_name, *args):
 def _carve(like, *nbytes):
     """Raw device pointers of consecutive 256-byte aligned regions of the stream's scratch buffer: the temporaries of ONE call
     (pair rows, partial statistics, an intermediate gradient, kernel workspaces) that never leave it."""
+    if torch.cuda.is_current_stream_capturing():
+        # Under capture `_scratch` hands out a fresh allocation from the graph's private pool; this function returns raw addresses and
+        # drops the tensor, so a later allocation of the same capture could be given the same block while kernels recorded earlier
+        # still use it.  The callers (the Conv3d + BatchNorm node) also rely on the library's per-stream ticket counters, which must
+        # not be baked into a graph that replays beside eager launches.  Neither is supported: fail instead of corrupting data.
+        raise RuntimeError("fusiontransformer_amd: the fused Conv3d + BatchNorm node cannot be captured into a HIP graph "
+                           "(its temporaries are carved from the stream's scratch buffer); run the LiDAR branch eagerly")
     offs, total = [], 0
     for n in nbytes:
         offs.append(total)

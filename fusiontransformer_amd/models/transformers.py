@@ -286,13 +286,22 @@ class Image2DTransformer(nn.Module):
             # This pass and its backward run eagerly.  A capture attempted AFTER an eager backward through these parameters
             # aborts the process inside hipStreamEndCapture on torch 2.10 / ROCm 7 (tools/probes/graph_recapture.py) -- an abort,
             # not an exception -- so from here on no NEW capture is attempted (already captured shapes keep replaying).
-            self.__dict__["_graph_capture_off"] = True
+            self._capture_off("an eager training pass ran through the trunk before the capture")
         x = self._embed(x)
         outputs = dict()
-        for i, block in enumerate(self.blocks):
-            if self.last_block is not None and i > self.last_block:
-                break
-            x = block(x)
+        live = [b for i, b in enumerate(self.blocks) if self.last_block is None or i <= self.last_block]
+        # Same residual-stream form as the captured segments (_TrunkSegment): the stream stays (r, p, pb) from block to block and a
+        # block's output is materialised only for the caller, so the eager trunk and the graphed trunk run the SAME kernels in the same
+        # order and agree to the last bit in every gradient (a per-block materialise would send the fc2 bias gradients of the inner
+        # blocks through autograd's fp32 sum_to instead of the fused LayerNorm backward's float64 column sums: a 2e-7 difference).
+        chained = x.is_cuda and all(b._fused(x) for b in live)
+        r, p, pb = x, None, None
+        for i, block in enumerate(live):
+            if chained:
+                r, p, pb = block.chain(r, p, pb)
+                x = _materialize(r, p, pb)
+            else:
+                x = block(x)
             if self.remove_tokens_outputs:
                 outputs[str(i)] = x[:, self.num_tokens:, :]
             else:
@@ -321,7 +330,13 @@ class Image2DTransformer(nn.Module):
         key = self._graph_key(x)
         if key not in cache:
             if self.__dict__.get("_graph_capture_off", False):
-                return None      # an eager training pass or a refused capture came before: never capture again (see forward_blocks)
+                # an eager training pass or a refused capture came before: never capture again (see forward_blocks); say so ONCE
+                if not self.__dict__.get("_graph_off_reported", False):
+                    import sys
+                    self.__dict__["_graph_off_reported"] = True
+                    print("[fusiontransformer_amd] ViT trunk runs eagerly for input %s: HIP-graph capture is off (%s)"
+                          % (tuple(x.shape), self.__dict__.get("_graph_off_reason", "unknown")), file=sys.stderr, flush=True)
+                return None
             try:
                 cache[key] = self._capture_segments(x)
             except Exception as err:   # capture refused (another thread touched the device, unsupported op, ...): run eagerly
@@ -329,8 +344,25 @@ class Image2DTransformer(nn.Module):
                 print("[fusiontransformer_amd] HIP-graph capture of the ViT trunk failed (%s: %s); running it eagerly from now on" % (type(err).__name__, err),
                       file=sys.stderr, flush=True)
                 cache[key] = None
-                self.__dict__["_graph_capture_off"] = True
+                self._capture_off("capture refused: %s: %s" % (type(err).__name__, err))
         return cache[key]
+
+    def _capture_off(self, reason):
+        if not self.__dict__.get("_graph_capture_off", False):
+            self.__dict__["_graph_capture_off"] = True
+            self.__dict__["_graph_off_reason"] = str(reason)
+
+    def graph_state(self):
+        """"on" (every shape seen so far replays as HIP graphs), "off:<reason>" (capture was switched off: later shapes run eagerly,
+        at a cost in speed only), "eager" (graph_taps not set), "idle" (nothing captured yet)."""
+        if not self.graph_taps:
+            return "eager"
+        if self.__dict__.get("_graph_capture_off", False):
+            return "off:" + self.__dict__.get("_graph_off_reason", "unknown")
+        cache = self.__dict__.get("_graph_cache") or {}
+        if not cache:
+            return "idle"
+        return "on" if all(v is not None for v in cache.values()) else "off:a capture fell back to eager execution"
 
     def _capture_segments(self, x):
         taps = sorted(int(t) for t in self.graph_taps)

@@ -70,3 +70,47 @@ def test_grad_reducer_world2_gloo():
     for rank, ok, rebuilt, nb in res:
         assert ok, f"rank {rank}: reduced gradients differ from the average of the local ones"
         assert rebuilt and nb > 1
+
+
+def _forced_worker(port, q):
+    """World size 1 with the collective path forced on: the all-reduce of one rank is the identity, so the reduced gradients must be the
+    local ones to the last bit, and every bucket must have gone through a collective."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    from fusiontransformer_amd.dist import GradReducer, init_process_group
+    with pytest.raises(RuntimeError):
+        GradReducer(torch.nn.Linear(2, 2), force_collectives=True)      # no process group yet
+    r, w, _ = init_process_group("gloo", force=True)
+    assert (r, w) == (0, 1) and dist.is_initialized()
+    torch.manual_seed(3)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+    twin = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+    twin.load_state_dict(model.state_dict())
+    red = GradReducer(model, bucket_mb=0.0005, force_collectives=True)
+    assert red.active and GradReducer(twin).active is False
+    calls = []
+    real = dist.all_reduce
+    dist.all_reduce = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    ok = True
+    for step in range(3):
+        x = torch.randn(5, 8)
+        twin.zero_grad()
+        twin(x).pow(2).sum().backward()
+        red.begin_step()
+        model(x).pow(2).sum().backward()
+        red.finish()
+        ok = ok and all(torch.equal(p.grad, t.grad) for p, t in zip(model.parameters(), twin.parameters()))
+    dist.all_reduce = real
+    q.put((ok, len(calls), len(red.buckets), red._rebuilt))
+    dist.destroy_process_group()
+
+
+def test_forced_collectives_at_world_size_one():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_worker, args=(_free_port(), q))
+    p.start()
+    ok, calls, nb, rebuilt = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert ok, "a one-rank all-reduce changed the gradients"
+    assert nb > 1 and rebuilt and calls >= 3 * nb, (calls, nb)

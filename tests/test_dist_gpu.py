@@ -100,3 +100,67 @@ def test_two_ranks_on_one_gpu_real_model_streams_and_graphs():
         assert captured, "the trunk was not running as HIP graphs"
     for p in procs:
         assert p.exitcode == 0
+
+
+def _rccl_one_rank_worker(port, q):
+    """The collective path of the N > 1 step on ONE GPU over the real backend: a one-rank RCCL communicator, `async_op` all-reduces
+    issued from the post-accumulate hooks while the two branch streams are still running the backward, `work.wait()` in finish().
+    An all-reduce over one rank is the identity, so every gradient and, after three Adam steps, every parameter must equal a twin's
+    that runs without any reducer -- bit for bit (reference wiring: modules/TorchpackInterface.py:44-81)."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        from fusiontransformer_amd.data.synth import make_batch
+        from fusiontransformer_amd.dist import GradReducer, init_process_group
+        from fusiontransformer_amd.models.build import build_model
+        from fusiontransformer_amd.trainer import TrainStep
+        from tests.helpers import product_inputs, small_cfg
+        init_process_group("nccl", force=True)
+        assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        cfg = small_cfg("middle")
+        torch.manual_seed(5)
+        model, _, _ = build_model(cfg)
+        twin, _, _ = build_model(cfg)
+        twin.load_state_dict(model.state_dict())
+        model, twin = model.cuda().train(), twin.cuda().train()
+        red = GradReducer(model, bucket_mb=8.0, force_collectives=True)
+        assert red.active
+        step, step_twin = TrainStep(cfg, model, grad_reducer=red), TrainStep(cfg, twin)
+        same_grads = True
+        for s in range(3):
+            pin = product_inputs(make_batch([30 + 2 * s, 31 + 2 * s], max_points=1800))
+            torch.manual_seed(9 + s)
+            step(pin)
+            torch.manual_seed(9 + s)
+            step_twin(pin)
+            torch.cuda.synchronize()
+            for (n, p), (_, t) in zip(model.named_parameters(), twin.named_parameters()):
+                if p.requires_grad:
+                    same_grads = same_grads and t.grad is not None and torch.equal(p.grad, t.grad)
+        same_params = all(torch.equal(p, t) for p, t in zip(model.parameters(), twin.parameters()))
+        ms = red.allreduce_ms(2)
+        captured = model.image_backbone.backbone.graph_state()
+        q.put(("ok", same_grads, same_params, red._rebuilt, len(red.buckets), ms, captured))
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put(("error", traceback.format_exc(), False, False, 0, None, ""))
+        raise
+
+
+def test_one_rank_rccl_collective_path_is_the_identity():
+    import multiprocessing as mp
+    ctx = mp.get_context("forkserver")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    status, same_grads, same_params, rebuilt, nb, ms, captured = q.get(timeout=600)
+    p.join(timeout=120)
+    assert status == "ok", same_grads
+    assert same_grads, "gradients after the one-rank RCCL all-reduce differ from the local ones"
+    assert same_params, "parameters after three steps differ from the twin without a reducer"
+    assert rebuilt and nb > 1 and ms is not None and ms > 0
+    assert captured == "on", captured
+    assert p.exitcode == 0

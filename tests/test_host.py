@@ -1,5 +1,7 @@
 """Host logic that needs no GPU: config loader, model factory / state_dict naming, synthetic
 generator, collate, and the refusal to run the product path without the GPU."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -160,3 +162,26 @@ def test_prepare_batch_is_a_no_op_off_the_gpu():
     lidar = SparseTensor(torch.zeros(4, 4), torch.zeros(4, 4, dtype=torch.int32))
     d = {"lidar": lidar}
     assert prepare_batch(model, d) is d and lidar.prepared is None
+
+
+def test_bench_self_launch_command_is_the_drivers_launcher_line():
+    """`python bench.py --gpus N` without WORLD_SIZE becomes the launcher itself: children under torch.distributed.run, one per GPU,
+    rendezvous on 127.0.0.1 (the reference: torchpack_run.sh:3 `torchpack dist-run -np N python train.py ...`)."""
+    import bench
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "3", "--warmup", "1"], port=29511)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    i = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    auto = bench.launch_command(2, [])
+    assert 1024 < int(auto[auto.index("--master-port") + 1]) < 65536
+
+
+def test_carve_refuses_to_run_under_stream_capture(monkeypatch):
+    """functional._carve returns raw addresses into the stream's scratch buffer; under HIP-graph capture that buffer would be a
+    fresh pool allocation freed on return, so the call must fail loudly instead."""
+    from fusiontransformer_amd import functional as Fn
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
+    with pytest.raises(RuntimeError, match="cannot be captured"):
+        Fn._carve(torch.zeros(1), 1024, 4096)
