@@ -240,7 +240,7 @@ def selfcheck(cfg, model, step, data, device, bf16, compare_grads):
     twin, _, _ = build_model(cfg)
     twin.load_state_dict(state)
     twin = twin.to(device).train()
-    twin.image_backbone.backbone.graph_taps = None
+    twin.image_backbone.backbone.use_graphs = False      # eager trunk, same segment structure
     twin.overlap_branches = False
     if bf16:
         twin.image_backbone.backbone.set_bf16(True)
@@ -313,6 +313,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher (the reference's counterpart is torchpack_run.sh:3)
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+
+    # stdout carries exactly ONE line, the JSON record: RCCL prints a version banner to stdout when its first communicator comes up, so
+    # file descriptor 1 points at stderr for the rest of the run and the record is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     from fusiontransformer_amd import functional as spf
     from fusiontransformer_amd.config import fusion_cfg
@@ -527,7 +533,8 @@ def main():
                                                         "image": "%dx%d" % (SHAPES["nuscenes"]["H"], SHAPES["nuscenes"]["W"])}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, np_batch)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if args.tune_gemm and rank == 0:
         from fusiontransformer_amd import gemm_tuning
         if gemm_tuning.save(rank):

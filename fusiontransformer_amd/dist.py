@@ -58,11 +58,11 @@ def init_process_group(backend=None, force=False):
 
 
 class _Bucket:
-    __slots__ = ("params", "flat", "pending", "work", "launched", "events")
+    __slots__ = ("params", "flat", "pending", "work", "launched", "streams")
 
     def __init__(self, params, flat):
         self.params, self.flat = params, flat
-        self.pending, self.work, self.launched, self.events = len(params), None, False, []
+        self.pending, self.work, self.launched, self.streams = len(params), None, False, {}
 
 
 class GradReducer:
@@ -79,6 +79,7 @@ class GradReducer:
         self.bucket_bytes = int(bucket_mb * 1024 * 1024)
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.step_idx = 0
+        self._comm = {}
         self.ready_order = []
         self._rebuilt = False
         self._record = False
@@ -150,22 +151,41 @@ class GradReducer:
             self._build(self._agree_on_order(order))
             self._rebuilt = True
         for b in self.buckets:
-            b.pending, b.work, b.launched, b.events = len(b.params), None, False, []
+            b.pending, b.work, b.launched, b.streams = len(b.params), None, False, {}
             b.flat.zero_()   # zero_grad for every gradient of the bucket in one fill
         self.next_to_launch = 0
         self._record = self.step_idx == 0
         if self._record:
             self.ready_order = []
 
+    def _comm_stream(self, device):
+        """The stream the exchange is issued from.  A COMPUTE stream must never wait for it: the model runs its two branches on two HIP
+        streams and a bucket holds gradients of both, so issuing the reduction from whichever stream delivered the bucket's last
+        gradient (round 2) made that branch's backward wait for the other branch's -- measured with a one-rank RCCL communicator on
+        MI355X: 27.6 -> 37.1 ms per step.  Only this stream waits."""
+        key = (device.type, device.index)
+        st = self._comm.get(key)
+        if st is None:
+            st = self._comm[key] = torch.cuda.Stream(device=device)
+        return st
+
     def _launch(self, b):
         b.launched = True
-        if self.active:
-            if b.flat.is_cuda:
-                # the model runs its two branches on two HIP streams, so a bucket's gradients may have
-                # been accumulated on different streams: order the reduction after every one of them
-                cur = torch.cuda.current_stream()
-                for ev in b.events:
-                    cur.wait_event(ev)
+        if not self.active:
+            return
+        if b.flat.is_cuda:
+            comm = self._comm_stream(b.flat.device)
+            # order the reduction after everything queued so far on every stream that accumulated one of the bucket's gradients
+            # (one event per stream, recorded now: later than strictly needed, but no event per gradient and nothing blocks compute)
+            for st in b.streams.values():
+                ev = torch.cuda.Event()
+                ev.record(st)
+                comm.wait_event(ev)
+            with torch.cuda.stream(comm):
+                if self.world > 1:
+                    b.flat.div_(self.world)
+                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        else:
             if self.world > 1:
                 b.flat.div_(self.world)
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
@@ -181,9 +201,8 @@ class GradReducer:
         b = self.buckets[self.bucket_of[p]]
         b.pending -= 1
         if p.is_cuda and self.active:
-            ev = torch.cuda.Event()
-            ev.record()          # on the stream that just accumulated this gradient
-            b.events.append(ev)
+            st = torch.cuda.current_stream()     # the stream that just accumulated this gradient
+            b.streams[st.cuda_stream] = st
         if self._rebuilt:  # overlap only once the bucket order follows the backward
             self._launch_ready_prefix()
 
@@ -194,7 +213,7 @@ class GradReducer:
                 self._launch(b)
         for b in self.buckets:
             if b.work is not None:
-                b.work.wait()
+                b.work.wait()     # NCCL: the CURRENT stream waits for the collective (no host block); gloo: the host waits
                 b.work = None
         self.step_idx += 1
 

@@ -182,9 +182,32 @@ class Block(nn.Module):
         return s2, self.mlp(h2, with_fc2_bias=False), self.mlp.fc2.bias
 
 
+class _Materialize(torch.autograd.Function):
+    """r + (p + pb) with pb broadcast over the rows; the bias gradient by ftx_colsum (float64, fixed order) instead of autograd's sum_to
+    reduction, which must not run inside a captured backward (see _LinearFn)."""
+
+    @staticmethod
+    def forward(ctx, r, p, pb):
+        return r + (p + pb)
+
+    @staticmethod
+    def backward(ctx, g):
+        gb = None
+        if ctx.needs_input_grad[2]:
+            g2 = g.reshape(-1, g.shape[-1])
+            if g2.is_cuda and g2.dtype == torch.float32 and g2.shape[1] % 4 == 0:
+                from .. import functional as spf
+                gb = spf.colsum(g2)
+            else:
+                gb = g2.sum(0)
+        return g, g, gb
+
+
 def _materialize(r, p, pb):
     """r + (p + pb): the residual stream of Block.chain as one tensor (bias first, as a GEMM's bias epilogue rounds it)."""
-    return r + (p + pb)
+    if p is None:
+        return r
+    return _Materialize.apply(r, p, pb)
 
 
 class PatchEmbed(nn.Module):
@@ -290,16 +313,18 @@ class Image2DTransformer(nn.Module):
         x = self._embed(x)
         outputs = dict()
         live = [b for i, b in enumerate(self.blocks) if self.last_block is None or i <= self.last_block]
-        # Same residual-stream form as the captured segments (_TrunkSegment): the stream stays (r, p, pb) from block to block and a
-        # block's output is materialised only for the caller, so the eager trunk and the graphed trunk run the SAME kernels in the same
-        # order and agree to the last bit in every gradient (a per-block materialise would send the fc2 bias gradients of the inner
-        # blocks through autograd's fp32 sum_to instead of the fused LayerNorm backward's float64 column sums: a 2e-7 difference).
-        chained = x.is_cuda and all(b._fused(x) for b in live)
+        # Same residual-stream form as the captured segments (_TrunkSegment): inside a segment the stream stays (r, p, pb) from block to
+        # block, at a segment end it becomes one tensor -- so the eager trunk and the graphed trunk run the SAME kernels in the same order
+        # and agree to the last bit in every gradient.  A block's output in between is materialised for the caller only.
+        ends = set(self._segment_ends()) if self.graph_taps else None      # no taps known: every block ends a segment
+        chained = x.is_cuda and ends is not None and all(b._fused(x) for b in live)
         r, p, pb = x, None, None
         for i, block in enumerate(live):
             if chained:
                 r, p, pb = block.chain(r, p, pb)
                 x = _materialize(r, p, pb)
+                if i in ends:
+                    r, p, pb = x, None, None
             else:
                 x = block(x)
             if self.remove_tokens_outputs:
@@ -324,7 +349,7 @@ class Image2DTransformer(nn.Module):
                 flags, grads, torch.cuda.current_device())
 
     def _graphed_segments(self, x):
-        if not self.graph_taps or not x.is_cuda or not self.training or not torch.is_grad_enabled():
+        if not self.graph_taps or not self.use_graphs or not x.is_cuda or not self.training or not torch.is_grad_enabled():
             return None
         cache = self.__dict__.setdefault("_graph_cache", {})
         key = self._graph_key(x)
@@ -355,7 +380,7 @@ class Image2DTransformer(nn.Module):
     def graph_state(self):
         """"on" (every shape seen so far replays as HIP graphs), "off:<reason>" (capture was switched off: later shapes run eagerly,
         at a cost in speed only), "eager" (graph_taps not set), "idle" (nothing captured yet)."""
-        if not self.graph_taps:
+        if not self.graph_taps or not self.use_graphs:
             return "eager"
         if self.__dict__.get("_graph_capture_off", False):
             return "off:" + self.__dict__.get("_graph_off_reason", "unknown")
@@ -364,18 +389,24 @@ class Image2DTransformer(nn.Module):
             return "idle"
         return "on" if all(v is not None for v in cache.values()) else "off:a capture fell back to eager execution"
 
-    def _capture_segments(self, x):
-        taps = sorted(int(t) for t in self.graph_taps)
-        # segment ends: every tap, and at most `graph_segment_blocks` blocks per graph -- the gradients of a segment become
-        # available together when its backward graph has run, so shorter segments keep the data-parallel bucket
-        # all-reduces (dist.GradReducer) overlapped with the rest of the backward
+    use_graphs = True    # False: same segment structure, executed eagerly (the twin of bench.py's selfcheck and of the bit-identity tests)
+
+    def _segment_ends(self):
+        """Last block of every trunk segment: every tap, and at most `graph_segment_blocks` blocks per segment -- the gradients of a
+        segment become available together when its backward graph has run, so shorter segments keep the data-parallel bucket
+        all-reduces (dist.GradReducer) overlapped with the rest of the backward."""
         ends, first = [], 0
-        for t in taps:
+        for t in sorted(int(t) for t in self.graph_taps):
             while t - first + 1 > self.graph_segment_blocks:
                 ends.append(first + self.graph_segment_blocks - 1)
                 first = ends[-1] + 1
             ends.append(t)
             first = t + 1
+        return ends
+
+    def _capture_segments(self, x):
+        taps = sorted(int(t) for t in self.graph_taps)
+        ends = self._segment_ends()
         segments, first = [], 0
         for e in ends:
             segments.append(_TrunkSegment(self, first, e, embed=(first == 0)))

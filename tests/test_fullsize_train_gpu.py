@@ -55,7 +55,7 @@ def test_three_bench_steps_against_the_float64_oracle_and_the_eager_twin():
     model, twin = model.cuda().train(), twin.cuda().train()
     trunk = model.image_backbone.backbone
     assert trunk.graph_taps, "the graphed trunk is expected to be the default in training"
-    twin.image_backbone.backbone.graph_taps = None     # eager trunk
+    twin.image_backbone.backbone.use_graphs = False     # eager trunk, same segment structure
     model.overlap_branches, twin.overlap_branches = True, False
     step, step_twin = TrainStep(cfg, model), TrainStep(cfg, twin)
     assert step.fused_loss and type(step.optimizer).__module__.endswith("optim"), "bench.py's loss kernel and one-launch Adam are expected"
