@@ -8,10 +8,11 @@ is the gradient average, ~108 M fp32 = 432 MB per step.
 
 Design for xGMI (point-to-point links, no switch): few large buckets (default
 64 MB) so each all-reduce amortises its launch and RCCL can spread it over all 7
-links; gradients live in flat per-bucket buffers (`p.grad` are views), so a
-bucket is reduced in place with no pack/unpack copies; a bucket's all-reduce is
-issued from the autograd hook of its last gradient and runs on RCCL's stream
-while the rest of the backward continues.  Buckets are launched strictly in
+links; each bucket is one flat buffer: when its last gradient has arrived the
+gradients are packed into it by ONE multi-tensor copy on the exchange stream,
+reduced in place, and `p.grad` become views of it (no unpack); the all-reduce is
+issued from the autograd hook of the bucket's last gradient, on a stream of its
+own, and runs while the rest of the backward continues.  Buckets are launched strictly in
 bucket order on every rank (collectives must match across ranks); the order is
 rebuilt after the first step from the gradient-ready order rank 0 observed
 (broadcast once, so every rank cuts identical buckets), so later steps overlap.  Parameters that never receive a gradient are frozen at model
@@ -58,10 +59,10 @@ def init_process_group(backend=None, force=False):
 
 
 class _Bucket:
-    __slots__ = ("params", "flat", "pending", "work", "launched", "streams")
+    __slots__ = ("params", "flat", "views", "pending", "work", "launched", "streams")
 
-    def __init__(self, params, flat):
-        self.params, self.flat = params, flat
+    def __init__(self, params, flat, views):
+        self.params, self.flat, self.views = params, flat, views
         self.pending, self.work, self.launched, self.streams = len(params), None, False, {}
 
 
@@ -114,14 +115,11 @@ class GradReducer:
         for g in groups:
             pad4 = lambda n: (n + 3) & ~3     # every gradient view starts on a 16-byte boundary (vector loads in ftx_adam_step)
             flat = torch.zeros(sum(pad4(p.numel()) for p in g), dtype=g[0].dtype, device=g[0].device)
-            off = 0
+            off, views = 0, []
             for p in g:
-                view = flat[off:off + p.numel()].view_as(p)
-                if p.grad is not None:
-                    view.copy_(p.grad)
-                p.grad = view
+                views.append(flat[off:off + p.numel()].view_as(p))
                 off += pad4(p.numel())
-            b = _Bucket(g, flat)
+            b = _Bucket(g, flat, views)
             for p in g:
                 self.bucket_of[p] = len(self.buckets)
             self.buckets.append(b)
@@ -152,7 +150,8 @@ class GradReducer:
             self._rebuilt = True
         for b in self.buckets:
             b.pending, b.work, b.launched, b.streams = len(b.params), None, False, {}
-            b.flat.zero_()   # zero_grad for every gradient of the bucket in one fill
+        for p in self.params:
+            p.grad = None    # autograd then MOVES each gradient into place (no add kernel per parameter); _launch packs the bucket
         self.next_to_launch = 0
         self._record = self.step_idx == 0
         if self._record:
@@ -169,9 +168,29 @@ class GradReducer:
             st = self._comm[key] = torch.cuda.Stream(device=device)
         return st
 
+    def _pack(self, b, comm=None):
+        """The bucket's gradients, as autograd left them in p.grad, copied into the flat buffer by one multi-tensor launch;
+        afterwards p.grad IS the view (the optimizer reads the reduced values there).  Round 2 kept p.grad as views all the time,
+        which turns every AccumulateGrad into a read-modify-write kernel of its own: ~330 extra launches per step."""
+        src, dst = [], []
+        for p, v in zip(b.params, b.views):
+            if p.grad is None:
+                v.zero_()            # no gradient this step: contributes 0 to the average (as DDP does)
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
+            if comm is not None:
+                for g in src:
+                    g.record_stream(comm)    # produced on a branch stream, read here: keep the allocator from recycling it early
+        for p, v in zip(b.params, b.views):
+            p.grad = v
+
     def _launch(self, b):
         b.launched = True
         if not self.active:
+            self._pack(b)
             return
         if b.flat.is_cuda:
             comm = self._comm_stream(b.flat.device)
@@ -182,10 +201,12 @@ class GradReducer:
                 ev.record(st)
                 comm.wait_event(ev)
             with torch.cuda.stream(comm):
+                self._pack(b, comm)
                 if self.world > 1:
                     b.flat.div_(self.world)
                 b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         else:
+            self._pack(b)
             if self.world > 1:
                 b.flat.div_(self.world)
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)

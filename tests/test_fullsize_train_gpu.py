@@ -19,10 +19,11 @@ from tests.helpers import oracle_inputs, product_inputs
 
 pytestmark = pytest.mark.gpu
 TOL_LOGIT, TOL_LOSS = 1e-3, 1e-4
-# worst per-parameter L2-relative gradient error against float64 measured on MI355X for this workload (gpurun_out/grad_parity_fullsize.json):
-# 6e-3 .. 1.3e-2 over the three steps (the fp32 oracle itself sits 1e-3 .. 5e-3 from float64 in this network); a wrong or
-# missing term, or a replay that reads a stale buffer, shows up as O(1)
-TOL_GRAD = 3e-2
+# worst per-parameter L2-relative gradient error against float64 measured on MI355X for this workload (profiles/r03_grad_parity_fullsize.json):
+# 1.9e-3, 3.2e-3, 1.1e-3 over the three steps (BatchNorm biases of the deep levels; 36-46 k points average the rounding noise down
+# from the 5e-3 .. 1.5e-2 of the 2-3 k-point tests); the bound is 3x the worst measured.  A wrong or missing term, or a replay that
+# reads a stale buffer, shows up as O(1)
+TOL_GRAD = 1e-2
 
 
 def _level_rows(coords, stride):
