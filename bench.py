@@ -355,6 +355,8 @@ def main():
     if args.bf16_forward:
         model.image_backbone.backbone.set_bf16(True)
     reducer = GradReducer(model, force_collectives=force_coll) if (world > 1 or force_coll) else None
+    if os.environ.get("FTX_NO_REDUCER") == "1" and world == 1:
+        reducer = None      # measurement aid: the process group exists, the step runs without the reducer
     step = TrainStep(cfg, model, metrics=(m2d, m3d), grad_reducer=reducer)
     batches = [build_inputs(cfg, args.batch, args.shape, rank, device, cycle=c) for c in range(max(1, args.cycle))]
     np_batch = batches[0][0]
@@ -403,6 +405,9 @@ def main():
         elapsed = float(t.item())
 
     allreduce_ms = None
+    if reducer is not None and rank == 0:
+        hs = reducer.hook_stats
+        log("reducer hooks: %s; per step %.3f ms of host time on the autograd thread" % (hs, hs["host_ms"] / max(reducer.step_idx, 1)))
     if reducer is not None:
         allreduce_ms = reducer.allreduce_ms(3)    # collective: every rank takes part; gradients are overwritten (next step zeroes them)
         barrier()
@@ -447,8 +452,8 @@ def main():
         out["rccl_ranks"] = (world if (_d.is_initialized() and _d.get_backend() == "nccl") else 0)
         out["multi_gpu"] = ("measured: %d ranks over RCCL" % world) if (world > 1 and out["rccl_ranks"] > 1) else "unmeasured in this run (one GPU)"
         out["collectives"] = ("none (single process, no process group)" if reducer is None else
-                              "%s backend, %d rank(s), %d flat buckets of <= 64 MB, async all-reduce from the autograd hooks%s"
-                              % (_d.get_backend(), world, len(reducer.buckets), " (forced at world size 1)" if world == 1 else ""))
+                              "%s backend, %d rank(s), %d flat buckets of <= %d MB, async all-reduce on an exchange stream, issued from the autograd hook of each bucket's last gradient%s"
+                              % (_d.get_backend(), world, len(reducer.buckets), reducer.bucket_bytes >> 20, " (forced at world size 1)" if world == 1 else ""))
         if roof is not None and args.attn == "ftx" and not args.no_attention_roofline:
             # The ViT trunk replays as HIP graphs, whose kernels cannot be bracketed by events from the host; the attention kernels are
             # timed here, standalone, at the workload's shape (same launches as inside the graphs), after the timed region.

@@ -7,8 +7,10 @@ data/collate.py:41-42), so ranks share nothing in the forward; the only exchange
 is the gradient average, ~108 M fp32 = 432 MB per step.
 
 Design for xGMI (point-to-point links, no switch): few large buckets (default
-64 MB) so each all-reduce amortises its launch and RCCL can spread it over all 7
-links; each bucket is one flat buffer: when its last gradient has arrived the
+128 MB: four per step) so each all-reduce amortises its launch, RCCL can spread
+it over all 7 links, and the host work of issuing a bucket -- which runs on the
+autograd thread, between two backward nodes -- happens three times per backward,
+not seven; each bucket is one flat buffer: when its last gradient has arrived the
 gradients are packed into it by ONE multi-tensor copy on the exchange stream,
 reduced in place, and `p.grad` become views of it (no unpack); the all-reduce is
 issued from the autograd hook of the bucket's last gradient, on a stream of its
@@ -21,6 +23,7 @@ stay per replica, as in the reference (no SyncBN anywhere)."""
 from __future__ import annotations
 
 import os
+import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL / cross-process device memory on this driver
 
@@ -59,17 +62,24 @@ def init_process_group(backend=None, force=False):
 
 
 class _Bucket:
-    __slots__ = ("params", "flat", "views", "pending", "work", "launched", "streams")
+    __slots__ = ("params", "flat", "views", "work", "launched", "tail_seen", "hold")
 
     def __init__(self, params, flat, views):
         self.params, self.flat, self.views = params, flat, views
-        self.pending, self.work, self.launched, self.streams = len(params), None, False, {}
+        self.work, self.launched, self.tail_seen, self.hold = None, False, False, None
 
 
 class GradReducer:
-    """Bucketed, overlapped gradient all-reduce (average) for `model`'s trainable parameters."""
+    """Bucketed, overlapped gradient all-reduce (average) for `model`'s trainable parameters.
 
-    def __init__(self, model, bucket_mb: float = 64.0, process_group=None, broadcast_params=True, force_collectives=False):
+    Step 0 runs with a hook on every parameter and records the order in which gradients become ready (and the streams they are
+    accumulated on); nothing overlaps yet.  From step 1 on the buckets follow that order (rank 0's, broadcast) and only the LAST
+    parameter of each bucket keeps a hook: ~330 Python hook calls per backward cost 2.5-3 ms per step on MI355X (measured with a
+    one-rank RCCL communicator: 27.6 ms without a reducer, 30.2-31.6 ms with per-parameter hooks, the collectives themselves free).
+    When a bucket's tail arrives, every gradient of the bucket is checked for presence (p.grad was set to None at the start of the
+    step); a bucket that is not complete -- the order changed -- simply waits for a later tail or for finish()."""
+
+    def __init__(self, model, bucket_mb: float = 128.0, process_group=None, broadcast_params=True, force_collectives=False):
         """force_collectives: issue the broadcasts and all-reduces even at world size 1 (needs an initialised process group,
         init_process_group(force=True)); the result is the identity, the code path is the N > 1 one."""
         self.pg = process_group
@@ -81,18 +91,20 @@ class GradReducer:
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.step_idx = 0
         self._comm = {}
+        self._streams = {}          # every stream a gradient was accumulated on (recorded in step 0)
         self.ready_order = []
         self._rebuilt = False
         self._record = False
+        self._handles = []
+        self.hook_stats = {"calls": 0, "early_launches": 0, "deferred": 0, "host_ms": 0.0}     # host time spent in the bucket-tail hooks (autograd thread)
         if self.active and broadcast_params:
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=0, group=self.pg)
         self._build(list(reversed(self.params)))
-        for p in self.params:
-            p.register_post_accumulate_grad_hook(self._on_grad_ready)
+        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad_ready) for p in self.params]
         # The hooks keep the AccumulateGrad nodes (created on the default stream) alive while the model's
         # branches run on their own streams; autograd then orders each accumulation after its producer
-        # stream, which is exactly what the bucket events rely on.  The advisory warning about it is noise.
+        # stream, which is exactly what the exchange relies on.  The advisory warning about it is noise.
         try:
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         except AttributeError:
@@ -100,7 +112,7 @@ class GradReducer:
 
     # -- bucket construction -------------------------------------------------
     def _build(self, ordered):
-        self.buckets, self.bucket_of = [], {}
+        self.buckets = []
         cur, cur_bytes = [], 0
         groups = []
         for p in ordered:
@@ -119,10 +131,7 @@ class GradReducer:
             for p in g:
                 views.append(flat[off:off + p.numel()].view_as(p))
                 off += pad4(p.numel())
-            b = _Bucket(g, flat, views)
-            for p in g:
-                self.bucket_of[p] = len(self.buckets)
-            self.buckets.append(b)
+            self.buckets.append(_Bucket(g, flat, views))
         self.next_to_launch = 0
 
     def _agree_on_order(self, order):
@@ -148,8 +157,12 @@ class GradReducer:
             order = self.ready_order + [p for p in reversed(self.params) if p not in seen]
             self._build(self._agree_on_order(order))
             self._rebuilt = True
+            for h in self._handles:
+                h.remove()
+            # one hook per bucket, on the parameter whose gradient arrived last in step 0
+            self._handles = [b.params[-1].register_post_accumulate_grad_hook(lambda p, i=i: self._on_bucket_tail(i)) for i, b in enumerate(self.buckets)]
         for b in self.buckets:
-            b.pending, b.work, b.launched, b.streams = len(b.params), None, False, {}
+            b.work, b.launched, b.tail_seen, b.hold = None, False, False, None
         for p in self.params:
             p.grad = None    # autograd then MOVES each gradient into place (no add kernel per parameter); _launch packs the bucket
         self.next_to_launch = 0
@@ -168,67 +181,91 @@ class GradReducer:
             st = self._comm[key] = torch.cuda.Stream(device=device)
         return st
 
-    def _pack(self, b, comm=None):
-        """The bucket's gradients, as autograd left them in p.grad, copied into the flat buffer by one multi-tensor launch;
-        afterwards p.grad IS the view (the optimizer reads the reduced values there).  Round 2 kept p.grad as views all the time,
-        which turns every AccumulateGrad into a read-modify-write kernel of its own: ~330 extra launches per step."""
+    def _pack(self, b, early=False):
+        """The bucket's gradients, as autograd left them in p.grad, copied into the flat buffer by one multi-tensor launch; p.grad
+        become the views in finish() (the optimizer reads the reduced values there).  Round 2 kept p.grad as views all the time,
+        which turns every AccumulateGrad into a read-modify-write kernel of its own: ~330 extra launches per step.
+        early=True (called from an autograd hook): returns False, with nothing done, when a gradient of the bucket is still missing."""
+        grads = [p.grad for p in b.params]
+        if early and any(g is None for g in grads):
+            return False
         src, dst = [], []
-        for p, v in zip(b.params, b.views):
-            if p.grad is None:
+        for g, v in zip(grads, b.views):
+            if g is None:
                 v.zero_()            # no gradient this step: contributes 0 to the average (as DDP does)
-            elif p.grad.data_ptr() != v.data_ptr():
-                src.append(p.grad)
+            else:
+                src.append(g)
                 dst.append(v)
-        if src:
+        if src and os.environ.get("FTX_REDUCER_NOPACK") != "1":     # measurement aid: 1 = host work only, no copy issued
             torch._foreach_copy_(dst, src)
-            if comm is not None:
-                for g in src:
-                    g.record_stream(comm)    # produced on a branch stream, read here: keep the allocator from recycling it early
-        for p, v in zip(b.params, b.views):
-            p.grad = v
+            # produced on a branch stream, read on the exchange stream: kept alive until finish() has made the step's stream wait for the
+            # exchange (tensor.record_stream would do, at an event per gradient when it is freed)
+            b.hold = src
+        return True
 
-    def _launch(self, b):
-        b.launched = True
+    def _launch(self, b, early=False):
+        """Everything here runs on the autograd thread when early=True, between two backward nodes: host time spent here delays the
+        issue of the rest of the backward one to one (measured: 7 early launches of ~0.4 ms each cost MORE than not overlapping the
+        exchange at all on one GPU), hence few, large buckets and nothing in this path that can wait for finish()."""
         if not self.active:
-            self._pack(b)
-            return
+            b.launched = self._pack(b, early)
+            return b.launched
         if b.flat.is_cuda:
             comm = self._comm_stream(b.flat.device)
-            # order the reduction after everything queued so far on every stream that accumulated one of the bucket's gradients
-            # (one event per stream, recorded now: later than strictly needed, but no event per gradient and nothing blocks compute)
-            for st in b.streams.values():
-                ev = torch.cuda.Event()
-                ev.record(st)
-                comm.wait_event(ev)
             with torch.cuda.stream(comm):
-                self._pack(b, comm)
+                # order the exchange after everything queued so far on every stream that accumulates gradients (one event per stream,
+                # recorded now: later than strictly needed, but no event per gradient and nothing blocks compute)
+                for st in self._streams.values():
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    comm.wait_event(ev)
+                if not self._pack(b, early):
+                    return False
                 if self.world > 1:
                     b.flat.div_(self.world)
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                if os.environ.get("FTX_REDUCER_NOCOMM") != "1":      # measurement aid: everything but the collective itself
+                    b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         else:
-            self._pack(b)
+            if not self._pack(b, early):
+                return False
             if self.world > 1:
                 b.flat.div_(self.world)
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        b.launched = True
+        return True
 
     def _launch_ready_prefix(self):
-        while self.next_to_launch < len(self.buckets) and self.buckets[self.next_to_launch].pending == 0:
-            self._launch(self.buckets[self.next_to_launch])
+        """Buckets go out strictly in bucket order on every rank (collectives are matched by issue order)."""
+        while self.next_to_launch < len(self.buckets):
+            b = self.buckets[self.next_to_launch]
+            if not b.tail_seen or not self._launch(b, early=True):
+                return
             self.next_to_launch += 1
 
     def _on_grad_ready(self, p):
+        """Step 0 (a hook on every parameter): learn the ready order and the accumulating streams; nothing is launched early."""
         if self._record:
             self.ready_order.append(p)
-        b = self.buckets[self.bucket_of[p]]
-        b.pending -= 1
-        if p.is_cuda and self.active:
+        if p.is_cuda:
             st = torch.cuda.current_stream()     # the stream that just accumulated this gradient
-            b.streams[st.cuda_stream] = st
-        if self._rebuilt:  # overlap only once the bucket order follows the backward
+            self._streams[st.cuda_stream] = st
+
+    def _on_bucket_tail(self, i):
+        t0 = time.perf_counter()
+        self.buckets[i].tail_seen = True
+        if os.environ.get("FTX_REDUCER_LATE") != "1":       # measurement aid: 1 = nothing goes out before finish()
+            before = self.next_to_launch
             self._launch_ready_prefix()
+            self.hook_stats["early_launches"] += self.next_to_launch - before
+            self.hook_stats["deferred"] += int(self.next_to_launch == before)
+        self.hook_stats["calls"] += 1
+        self.hook_stats["host_ms"] += 1e3 * (time.perf_counter() - t0)
 
     def finish(self):
         """Call after backward: launches what has not gone out yet (in bucket order) and waits."""
+        if self.buckets and self.buckets[0].flat.is_cuda:
+            cur = torch.cuda.current_stream()
+            self._streams[cur.cuda_stream] = cur
         for b in self.buckets:
             if not b.launched:
                 self._launch(b)
@@ -236,6 +273,13 @@ class GradReducer:
             if b.work is not None:
                 b.work.wait()     # NCCL: the CURRENT stream waits for the collective (no host block); gloo: the host waits
                 b.work = None
+        if self.active and self.buckets and self.buckets[0].flat.is_cuda:
+            # packs without a collective behind them (FTX_REDUCER_NOCOMM) and the held gradients: the step's stream waits for the exchange stream
+            torch.cuda.current_stream().wait_stream(self._comm_stream(self.buckets[0].flat.device))
+        for b in self.buckets:
+            b.hold = None
+            for p, v in zip(b.params, b.views):
+                p.grad = v
         self.step_idx += 1
 
     def allreduce_ms(self, reps: int = 3):
