@@ -20,6 +20,10 @@ _i32, _i64, _f32, _vp, _sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_si
 SIGNATURES = {
     "ftx_version": (C.c_int, []),
     "ftx_last_error": (C.c_char_p, []),
+    "ftx_stream_scratch_bytes": (_sz, []),
+    "ftx_stream_scratch_attach": (C.c_int, [_vp, _vp, _sz]),
+    "ftx_stream_scratch_reset": (C.c_int, [_vp]),
+    "ftx_stream_scratch_release": (C.c_int, [_vp]),
     "ftx_hash": (C.c_int, [_vp, _i64, _vp, _vp]),
     "ftx_hash_kernel": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp]),
     "ftx_floor_coords": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
@@ -56,10 +60,6 @@ SIGNATURES = {
     "ftx_sample_down_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ftx_spconv_pairs_gemm": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "ftx_spconv_pairs_gemm_scatter": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
-    "ftx_spconv_set_gemm_variant": (None, [_i32]),
-    "ftx_spconv_get_gemm_variant": (_i32, []),
-    "ftx_spconv_set_split": (None, [_i32]),
-    "ftx_spconv_get_split": (_i32, []),
     "ftx_rows_gemm": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "ftx_spconv_reduce": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "ftx_spconv_reduce_stats_blocks": (_i32, [_i64, _i32]),
@@ -67,6 +67,8 @@ SIGNATURES = {
     "ftx_bn_train_fwd_totals": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ftx_spconv_pairs_wgrad_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "ftx_spconv_pairs_wgrad": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "ftx_spconv_wgrad_resident_blocks": (_i32, [_i32, _i32]),
+    "ftx_spconv_wgrad_table_blocks": (_i32, [_i32, _i32, _i32, _i32]),
     "ftx_bn_workspace_bytes": (_sz, [_i64, _i32]),
     "ftx_bn_train_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ftx_bn_eval_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i32, _i32, _vp, _vp]),
@@ -81,7 +83,8 @@ SIGNATURES = {
     "ftx_attn_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     "ftx_attn_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "ftx_attn_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
-    "ftx_attn_set_config": (C.c_int, [_i32, _i32]),
+    "ftx_attn_fwd_tiled": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _i32, _i32, _vp]),
+    "ftx_attn_bwd_tiled": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _i32, _i32, _vp]),
     "ftx_fusion_loss_workspace_bytes": (_sz, []),
     "ftx_fusion_loss": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ftx_fusion_loss_mix": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

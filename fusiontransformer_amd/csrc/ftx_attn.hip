@@ -480,26 +480,19 @@ static int attn_check(const char *who, int b, int t, int h, int d) {
   return FTX_OK;
 }
 
-// (QW, SPLIT) of a launch.  0 = pick from the number of 32-row wave-tiles (see the comment above attn_fwd_kernel).
-static int g_attn_qw = 0, g_attn_split = 0;
-extern "C" int ftx_attn_set_config(int32_t qw, int32_t split) {
-  const bool ok = (qw == 0 && split == 0) || (qw == 4 && split == 2) || (qw == 2 && (split == 2 || split == 4)) ||
-                  (qw == 1 && (split == 2 || split == 4 || split == 8));
-  FTX_REQUIRE(ok, "ftx_attn_set_config: (%d, %d) is not a built configuration", qw, split);
-  g_attn_qw = qw;
-  g_attn_split = split;
-  return FTX_OK;
-}
+// (QW, SPLIT) of a launch: an explicit, built tiling from the caller (ftx_attn_fwd_tiled / ftx_attn_bwd_tiled: tests and tools/bench_attn.py
+// walk them), or (0, 0) = chosen here from the number of 32-row wave-tiles against the SIMDs of an MI355X (256 CUs x 4; a constant, not a
+// device query: the choice -- hence nothing a caller can observe but time -- must not depend on the environment).  No process-wide state.
 // Measured at 578 tokens x 12 heads (tools/bench_attn.py, us fwd / bwd): batch 1 (228 wave-tiles) (4,2) 52 / 170, (1,8) 21 / 75,
 // (1,4) 23 / 70; batch 2 (4,2) 52 / 170, (2,4) 34 / 103; batch 4 (4,2) 54 / 174, (2,4) 65 / 199; batch 8 (4,2) 106 / 342, others slower.
+static bool attn_tiling_built(int qw, int split) {
+  return (qw == 0 && split == 0) || (qw == 4 && split == 2) || (qw == 2 && (split == 2 || split == 4)) ||
+         (qw == 1 && (split == 2 || split == 4 || split == 8));
+}
 static void attn_config(int b, int t, int h, bool backward, int &qw, int &split) {
-  if (g_attn_qw) {
-    qw = g_attn_qw;
-    split = g_attn_split;
-    return;
-  }
+  if (qw != 0) return;   // explicit
   const int64_t wave_tiles = (int64_t)ceil_div(t, 32) * h * b;
-  const int64_t simds = 4 * (int64_t)device_cus();
+  const int64_t simds = 4 * 256;
   if (wave_tiles * 4 <= simds) { qw = 1; split = backward ? 4 : 8; }   // a quarter of the SIMDs or fewer: shortest key loop
   else if (wave_tiles * 2 <= simds) { qw = 2; split = 4; }
   else { qw = 4; split = 2; }
@@ -516,15 +509,20 @@ static void attn_config(int b, int t, int h, bool backward, int &qw, int &split)
     else KERNEL<1, 8><<<grid, 512, 0, st>>>(__VA_ARGS__);                                                        \
   } while (0)
 
-extern "C" int ftx_attn_fwd(const float *qkv, int32_t b, int32_t t, int32_t h, int32_t d, float scale, float *out, float *lse, void *stream) {
+extern "C" int ftx_attn_fwd_tiled(const float *qkv, int32_t b, int32_t t, int32_t h, int32_t d, float scale, float *out, float *lse, int32_t qw,
+                                  int32_t split, void *stream) {
   int rc = attn_check("ftx_attn_fwd", b, t, h, d);
   if (rc != FTX_OK) return rc;
   FTX_REQUIRE(qkv && out && lse, "ftx_attn_fwd: null pointer");
+  FTX_REQUIRE(attn_tiling_built(qw, split), "ftx_attn_fwd_tiled: (%d, %d) is not a built tiling", qw, split);
   hipStream_t st = (hipStream_t)stream;
-  int qw, split;
   attn_config(b, t, h, false, qw, split);
   ATTN_DISPATCH(attn_fwd_kernel, qkv, t, h, scale, out, lse);
   return check_launch("ftx_attn_fwd");
+}
+
+extern "C" int ftx_attn_fwd(const float *qkv, int32_t b, int32_t t, int32_t h, int32_t d, float scale, float *out, float *lse, void *stream) {
+  return ftx_attn_fwd_tiled(qkv, b, t, h, d, scale, out, lse, 0, 0, stream);
 }
 
 extern "C" size_t ftx_attn_bwd_workspace_bytes(int32_t b, int32_t t, int32_t h) {
@@ -532,11 +530,13 @@ extern "C" size_t ftx_attn_bwd_workspace_bytes(int32_t b, int32_t t, int32_t h) 
   return sizeof(float) * (size_t)b * t * h + 256;
 }
 
-extern "C" int ftx_attn_bwd(const float *qkv, const float *out, const float *grad_out, const float *lse, int32_t b, int32_t t, int32_t h,
-                            int32_t d, float scale, float *grad_qkv, void *workspace, size_t workspace_bytes, void *stream) {
+extern "C" int ftx_attn_bwd_tiled(const float *qkv, const float *out, const float *grad_out, const float *lse, int32_t b, int32_t t, int32_t h,
+                                  int32_t d, float scale, float *grad_qkv, void *workspace, size_t workspace_bytes, int32_t qw, int32_t split,
+                                  void *stream) {
   int rc = attn_check("ftx_attn_bwd", b, t, h, d);
   if (rc != FTX_OK) return rc;
   FTX_REQUIRE(qkv && out && grad_out && lse && grad_qkv && workspace, "ftx_attn_bwd: null pointer");
+  FTX_REQUIRE(attn_tiling_built(qw, split), "ftx_attn_bwd_tiled: (%d, %d) is not a built tiling", qw, split);
   if (workspace_bytes < ftx_attn_bwd_workspace_bytes(b, t, h)) {
     set_error("ftx_attn_bwd: workspace %zu < required %zu", workspace_bytes, ftx_attn_bwd_workspace_bytes(b, t, h));
     return FTX_EWORKSPACE;
@@ -545,9 +545,13 @@ extern "C" int ftx_attn_bwd(const float *qkv, const float *out, const float *gra
   float *delta = (float *)workspace;
   const int64_t rows = (int64_t)b * t * h;
   attn_delta_kernel<<<(unsigned)ceil_div(rows * 16, 256), 256, 0, st>>>(out, grad_out, rows, t, h, delta);
-  int qw, split;
   attn_config(b, t, h, true, qw, split);
   ATTN_DISPATCH(attn_bwd_kv_kernel, qkv, grad_out, lse, delta, t, h, scale, grad_qkv);
   ATTN_DISPATCH(attn_bwd_q_kernel, qkv, grad_out, lse, delta, t, h, scale, grad_qkv);
   return check_launch("ftx_attn_bwd");
+}
+
+extern "C" int ftx_attn_bwd(const float *qkv, const float *out, const float *grad_out, const float *lse, int32_t b, int32_t t, int32_t h,
+                            int32_t d, float scale, float *grad_qkv, void *workspace, size_t workspace_bytes, void *stream) {
+  return ftx_attn_bwd_tiled(qkv, out, grad_out, lse, b, t, h, d, scale, grad_qkv, workspace, workspace_bytes, 0, 0, stream);
 }

@@ -6,39 +6,102 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <utility>
 #include "ftx_common.h"
 #include "ftx_lastblock.h"
 
 using namespace ftx;
 
+// ---- per-(device, stream) ticket buffer (ftx_lastblock.h) ------------------------------------------------------------------------
+// The statistics kernels hand their column totals to "the last block to finish"; the tickets and the group rows live in a small
+// buffer that belongs to ONE stream of ONE device (launches of a stream are serialised, the last user of a counter puts it back to
+// zero).  The CALLER can own it: ftx_stream_scratch_bytes() / ftx_stream_scratch_attach(stream, ptr, bytes) hand the library a buffer
+// of the caller's, ftx_stream_scratch_reset(stream) clears the tickets (after a kernel died mid-flight), ftx_stream_scratch_release
+// gives it back.  Only a stream nobody attached a buffer to gets a library allocation, at first use (freed by release).
 namespace ftx {
+namespace {
+struct ScratchEntry {
+  StreamScratch sc;
+  void *owned;      // non-null: allocated here (hipMalloc), freed by release
+};
+std::mutex g_scratch_mu;
+std::map<std::pair<int, hipStream_t>, ScratchEntry> g_scratch;
+
+constexpr size_t scratch_counter_bytes() { return 512 * ((sizeof(uint32_t) * (1 + LB_MAX_GROUPS) + 511) / 512); }
+constexpr size_t scratch_group_bytes() { return sizeof(double) * (size_t)LB_MAX_GROUPS * 2 * LB_MAX_COLS; }
+
+int current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) (void)hipGetLastError();
+  return dev;
+}
+}  // namespace
+
 StreamScratch stream_scratch(hipStream_t st) {
-  static std::mutex mu;
-  static std::map<hipStream_t, StreamScratch> pool;
-  std::lock_guard<std::mutex> lock(mu);
-  auto it = pool.find(st);
-  if (it != pool.end()) return it->second;
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  const auto key = std::make_pair(current_device(), st);     // the legacy stream has the same handle on every device
+  auto it = g_scratch.find(key);
+  if (it != g_scratch.end()) return it->second.sc;
   StreamScratch sc{nullptr, nullptr};
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
-    set_error("stream_scratch: first use of a stream inside a capture (run the op once on that stream before capturing)");
+    set_error("stream_scratch: first use of a stream inside a capture (attach a buffer, or run the op once on that stream, before capturing)");
     return sc;
   }
   (void)hipGetLastError();
-  const size_t cbytes = 512 * ((sizeof(uint32_t) * (1 + LB_MAX_GROUPS) + 511) / 512);
-  const size_t gbytes = sizeof(double) * (size_t)LB_MAX_GROUPS * 2 * LB_MAX_COLS;
   char *base = nullptr;
-  if (hipMalloc((void **)&base, cbytes + gbytes) != hipSuccess || hipMemsetAsync(base, 0, cbytes, st) != hipSuccess) {
+  if (hipMalloc((void **)&base, scratch_counter_bytes() + scratch_group_bytes()) != hipSuccess ||
+      hipMemsetAsync(base, 0, scratch_counter_bytes(), st) != hipSuccess) {
     set_error("stream_scratch: cannot allocate the per-stream ticket buffer (%s)", hipGetErrorString(hipGetLastError()));
     if (base) (void)hipFree(base);
     return sc;
   }
   sc.counters = (uint32_t *)base;
-  sc.gpart = (double *)(base + cbytes);
-  pool[st] = sc;
+  sc.gpart = (double *)(base + scratch_counter_bytes());
+  g_scratch[key] = ScratchEntry{sc, base};
   return sc;
 }
 }  // namespace ftx
+
+extern "C" size_t ftx_stream_scratch_bytes(void) { return scratch_counter_bytes() + scratch_group_bytes(); }
+
+extern "C" int ftx_stream_scratch_attach(void *stream, void *buffer, size_t bytes) {
+  FTX_REQUIRE(buffer && ((uintptr_t)buffer & 255) == 0, "ftx_stream_scratch_attach: the buffer must be non-null and 256-byte aligned");
+  FTX_REQUIRE(bytes >= ftx_stream_scratch_bytes(), "ftx_stream_scratch_attach: %zu bytes < ftx_stream_scratch_bytes() = %zu", bytes, ftx_stream_scratch_bytes());
+  hipStream_t st = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  const auto key = std::make_pair(current_device(), st);
+  if (hipMemsetAsync(buffer, 0, scratch_counter_bytes(), st) != hipSuccess) return check_launch("ftx_stream_scratch_attach memset");
+  auto it = g_scratch.find(key);
+  if (it != g_scratch.end() && it->second.owned) {
+    // kernels already queued on the stream may still use the library's buffer: free it when they are done
+    if (hipStreamSynchronize(st) != hipSuccess) (void)hipGetLastError();
+    (void)hipFree(it->second.owned);
+  }
+  StreamScratch sc{(uint32_t *)buffer, (double *)((char *)buffer + scratch_counter_bytes())};
+  g_scratch[key] = ScratchEntry{sc, nullptr};
+  return FTX_OK;
+}
+
+extern "C" int ftx_stream_scratch_reset(void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  auto it = g_scratch.find(std::make_pair(current_device(), st));
+  if (it == g_scratch.end()) return FTX_OK;      // nothing to clear
+  if (hipMemsetAsync(it->second.sc.counters, 0, scratch_counter_bytes(), st) != hipSuccess) return check_launch("ftx_stream_scratch_reset");
+  return FTX_OK;
+}
+
+extern "C" int ftx_stream_scratch_release(void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  auto it = g_scratch.find(std::make_pair(current_device(), st));
+  if (it == g_scratch.end()) return FTX_OK;
+  if (hipStreamSynchronize(st) != hipSuccess) (void)hipGetLastError();      // the buffer goes back to its owner: nothing may still use it
+  if (it->second.owned) (void)hipFree(it->second.owned);
+  g_scratch.erase(it);
+  return FTX_OK;
+}
 
 // Grid of the statistics passes.  They stream 1-3 row matrices once and are bound by loads in flight, not by bytes: at 128 rows per
 // block the 81k-row level ran 635 blocks (2.5 per CU) and reached 1.7 TB/s; FTX_BN_ROWS / FTX_BN_MAX_BLOCKS keep the knobs measurable.

@@ -29,20 +29,6 @@ inline unsigned grid_for(int64_t work, int block) {
   return (unsigned)g;
 }
 
-// Compute units of the current device (256 on MI355X); 256 if the query fails.
-inline int device_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) {
-      (void)hipGetLastError();
-      n = 256;
-    }
-    cus = n;
-  }
-  return cus;
-}
-
 #define FTX_REQUIRE(cond, ...)                 \
   do {                                         \
     if (!(cond)) {                             \

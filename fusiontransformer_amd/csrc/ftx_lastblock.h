@@ -6,10 +6,17 @@
 // gpart[group], and the last group to finish sums the group rows in group order and hands the two totals of every column to
 // `fin`.  WHICH block does the summing depends on timing; the order of every sum does not, so the totals are bit-reproducible.
 //
-// Tickets live in a small per-stream buffer owned by the library (stream_scratch): launches of one stream are serialised, and the
-// block that uses a counter last puts it back to zero, so the buffer is always clean between kernels.
+// Tickets live in a small buffer per (device, stream) -- the caller's (ftx_stream_scratch_attach) or, for a stream nobody attached one
+// to, the library's: launches of one stream are serialised, and the block that uses a counter last puts it back to zero, so the buffer
+// is clean between kernels.  A kernel that dies mid-flight leaves tickets behind: ftx_stream_scratch_reset(stream) clears them, and a
+// dirty ticket is caught by the device-side assert in last_block_totals instead of producing stale totals silently.
 #pragma once
+#include <assert.h>
 #include "ftx_common.h"
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "ftx_lastblock.h relies on gfx9 (CDNA) memory-instruction semantics: sc1 write-through stores and vmcnt-counted store acknowledgements"
+#endif
 
 namespace ftx {
 
@@ -30,6 +37,23 @@ StreamScratch stream_scratch(hipStream_t st);
 // tickets -- moves by RELAXED atomic stores / loads / adds at agent scope, which go through to the coherence point (sc1) and leave
 // the caches alone; "my stores are done" is an explicit s_waitcnt vmcnt(0) before the barrier that precedes
 // the block's ticket, and the ticket's returned value gates the loads of the block that sums.
+//
+// What each step relies on (gfx950 ISA as emitted -- the disassembly lines are in profiles/r03_lastblock_isa.txt):
+//  * lb_store  -> global_store_dwordx2 ... sc1           an agent-scope store: written THROUGH the non-coherent per-XCD L2 to the memory
+//                                                        side (MALL / HBM), where every XCD sees it; nothing is left dirty in a cache
+//  * lb_stores_done -> s_waitcnt vmcnt(0) ; s_barrier    on gfx9 vmcnt counts stores as well as loads and a store is counted down when
+//                                                        the memory side has ACKNOWLEDGED it, so after the barrier every partial row of
+//                                                        the block is visible device-wide.  (This is the hardware meaning of a release at
+//                                                        agent scope minus the L2 write-back, which has nothing to write back here because
+//                                                        all cross-block data went out with sc1.)  Outside the HIP memory model; gfx9 only.
+//  * lb_ticket -> global_atomic_add ... sc0 (returning)  an RMW atomic at agent scope: always executed at the device's coherence point
+//                                                        (RMW atomics bypass the non-coherent caches by themselves; an sc1 bit on an
+//                                                        atomic would mean SYSTEM scope), in ticket order: the block that reads gsize-1
+//                                                        knows every other block of the group took its ticket AFTER its own stores were
+//                                                        acknowledged
+//  * lb_load   -> global_load_dwordx2 ... sc1            an agent-scope load: misses the XCD's L2 on purpose and reads the memory side,
+//                                                        so it cannot return a stale line; issued after the ticket's return value
+//                                                        (s_waitcnt + the branch on s_last) -- the acquire side
 __device__ inline void lb_store(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline double lb_load(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline uint32_t lb_ticket(uint32_t *p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -86,7 +110,11 @@ __device__ inline void last_block_totals(const double *part, int nb, int c, Stre
   const int gsize = nb - g0 < LB_GROUP ? nb - g0 : LB_GROUP;
   double *slices = lds, *tot = lds + 256;
   lb_stores_done();
-  if (tid == 0) s_last = lb_ticket(&sc.counters[1 + group]) == (uint32_t)gsize - 1u;
+  if (tid == 0) {
+    const uint32_t ticket = lb_ticket(&sc.counters[1 + group]);
+    assert(ticket < (uint32_t)gsize && "ftx: dirty BatchNorm ticket (a kernel died on this stream? call ftx_stream_scratch_reset)");
+    s_last = ticket == (uint32_t)gsize - 1u;
+  }
   __syncthreads();
   if (!s_last) return;
   lb_column_sums(part + (int64_t)g0 * c2, gsize, c2, slices, tot);
@@ -94,7 +122,9 @@ __device__ inline void last_block_totals(const double *part, int nb, int c, Stre
   lb_stores_done();
   if (tid == 0) {
     __hip_atomic_store(&sc.counters[1 + group], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = lb_ticket(&sc.counters[0]) == (uint32_t)ngroups - 1u;
+    const uint32_t ticket = lb_ticket(&sc.counters[0]);
+    assert(ticket < (uint32_t)ngroups && "ftx: dirty BatchNorm group ticket (call ftx_stream_scratch_reset)");
+    s_last = ticket == (uint32_t)ngroups - 1u;
   }
   __syncthreads();
   if (!s_last) return;

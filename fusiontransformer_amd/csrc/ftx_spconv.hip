@@ -361,74 +361,18 @@ static void launch_pairs_gemm(int nt, dim3 grid, hipStream_t st, const float *A,
 }
 
 #include "ftx_lastblock.h"
-#include "ftx_spconv_dma.h"
-#include "ftx_spconv_split.h"
-#include "ftx_spconv_pc.h"
 
-// Arithmetic of the matrix products of the sparse convolution: 0 = exact-f32 MFMA (default), 1 = three-way bf16 operand split on the
-// bf16 matrix cores, f32-equivalent accuracy (ftx_spconv_split.h).  Process-wide switch; FTX_SPCONV_SPLIT=1 sets the initial value.
-static int g_split = -1;
-static bool split_on() {
-  if (g_split < 0) g_split = getenv("FTX_SPCONV_SPLIT") ? (atoi(getenv("FTX_SPCONV_SPLIT")) != 0) : 0;
-  return g_split != 0;
-}
-extern "C" void ftx_spconv_set_split(int32_t on) { g_split = on ? 1 : 0; }
-extern "C" int32_t ftx_spconv_get_split(void) { return split_on() ? 1 : 0; }
-
-// Producer / consumer kernel (ftx_spconv_pc.h): whole 32-channel chunks and whole column tiles only.  FTX_GEMM_PC=1 selects it.
-// Pair-GEMM kernel variant: 0 register-staged tile kernel (default), 1 LDS-DMA tile kernel, 2 producer / consumer kernel.  All three are
-// exact-f32 and bit-identical; ftx_spconv_set_gemm_variant() switches at run time, FTX_GEMM_DMA=1 / FTX_GEMM_PC=1 set the initial value.
-static int g_gemm_variant = -1;
-static int gemm_variant() {
-  if (g_gemm_variant < 0) {
-    int v = 0;
-    if (getenv("FTX_GEMM_DMA") && atoi(getenv("FTX_GEMM_DMA"))) v = 1;
-    if (getenv("FTX_GEMM_PC") && atoi(getenv("FTX_GEMM_PC"))) v = 2;
-    g_gemm_variant = v;
-  }
-  return g_gemm_variant;
-}
-extern "C" void ftx_spconv_set_gemm_variant(int32_t v) { g_gemm_variant = (v >= 0 && v <= 2) ? v : 0; }
-extern "C" int32_t ftx_spconv_get_gemm_variant(void) { return gemm_variant(); }
-
-static bool gemm_use_pc(int64_t n_rows, int ca, int co, int nt) {
-  return gemm_variant() == 2 && n_rows >= 1 && ca % 32 == 0 && co % (32 * nt) == 0;
-}
-static unsigned pc_blocks() {
-  int dev = 0, n = 0;
-  static int cus = 0;
-  if (cus == 0) {
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) {
-      (void)hipGetLastError();
-      n = 256;
-    }
-    cus = n;
-  }
-  return (unsigned)cus;
-}
-
+// One pair-GEMM kernel ships.  The LDS-DMA, producer / consumer and bf16x3 variants of rounds 1-2 each tied or lost against it
+// (DESIGN.md section 8); their sources live under tools/probes/spconv_variants/ and are not part of libftx.so.  Nothing in this file
+// is selected by process-wide mutable state or by a device query: tile shapes and workspace sizes are functions of the arguments.
 static int gemm_nt(int co) {
   int nt = co >= 128 ? 4 : (co + 31) / 32;
   if (co > 128 && co % 96 == 0 && co % 128 != 0) nt = 3;
   return nt;
 }
 
-// Measured on MI355X (profiles/r01_spconv_layer_micro.txt workload): 256-pair tiles (RT = 2) are 5-30 % SLOWER
-// than 128-pair tiles on every layer -- the extra accumulators cut occupancy to 1-2 waves per SIMD and
-// the kernel is latency-, not W-traffic-bound.  RT = 2 stays selectable (FTX_GEMM_RT=2) as a tuning aid.
-static int gemm_rt(int64_t n_pairs, int kvol, int ca, int co) {
-  static const int forced = getenv("FTX_GEMM_RT") ? atoi(getenv("FTX_GEMM_RT")) : 0;
-  return forced == 2 ? 2 : 1;
-}
-
-// The LDS-DMA kernel (ftx_spconv_dma.h) takes whole 32-channel chunks and whole column tiles; everything else (the
-// 4-channel stem, the class heads) stays on the register-staged kernel.  Measured on MI355X over the 20 layers of
-// tools/bench_spconv.py it ties the register-staged kernel (891 vs 903 us forward, 911 vs 893 us dgrad: 3-5 % faster on
-// the deep levels, 2-3 % slower on level 0), so it is an opt-in tuning alternative: FTX_GEMM_DMA=1.
-static int gemm_variant();
-static bool gemm_use_dma(int64_t n_rows, int ca, int co, int nt) {
-  return gemm_variant() == 1 && n_rows >= 1 && ca % 32 == 0 && co % (32 * nt) == 0;
-}
+// Measured on MI355X (profiles/r01_spconv_layer_micro.txt workload): 256-pair tiles (RT = 2) are 5-30 % SLOWER than 128-pair tiles on every
+// layer -- the extra accumulators cut occupancy to 1-2 waves per SIMD and the kernel is latency-, not W-traffic-bound: RT = 1 everywhere.
 
 extern "C" int ftx_spconv_pairs_gemm(const float *A, int64_t rows_a, const int32_t *gather, const float *W, int32_t w_transposed,
                                      const int32_t *koff, int64_t n_pairs, int32_t ca, int32_t co, int32_t kvol, float *tmp, void *stream) {
@@ -437,22 +381,10 @@ extern "C" int ftx_spconv_pairs_gemm(const float *A, int64_t rows_a, const int32
   if (n_pairs == 0) return FTX_OK;
   FTX_REQUIRE(A && gather && W && koff && tmp && rows_a >= 1, "ftx_spconv_pairs_gemm: null pointer or empty operand");
   hipStream_t st = (hipStream_t)stream;
-  const int nt = gemm_nt(co), rt = gemm_rt(n_pairs, kvol, ca, co);
-  const unsigned tiles_ub = (unsigned)(ceil_div(n_pairs, TILE_P * rt) + kvol);  // sum_k ceil(cnt_k/tile) <= P/tile + kvol
+  const int nt = gemm_nt(co);
+  const unsigned tiles_ub = (unsigned)(ceil_div(n_pairs, TILE_P) + kvol);  // sum_k ceil(cnt_k/tile) <= P/tile + kvol
   dim3 grid(tiles_ub, (unsigned)ceil_div(co, 32 * nt));
-  if (split_on()) {
-    dim3 g1((unsigned)(ceil_div(n_pairs, TILE_P) + kvol), grid.y);
-    split::launch(nt, g1, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0, nullptr, 0);
-  } else if (gemm_use_pc(n_pairs, ca, co, nt)) {
-    FTX_REQUIRE(pc::dispatch(nt, pc_blocks(), st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0, nullptr, 0) == 0,
-                "ftx_spconv_pairs_gemm: could not configure the producer / consumer kernel");
-  } else if (rt == 1 && gemm_use_dma(n_pairs, ca, co, nt)) {
-    FTX_REQUIRE(dma::dispatch(nt, grid, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0) == 0,
-                "ftx_spconv_pairs_gemm: could not configure the LDS-DMA kernel");
-  } else if (rt == 2)
-    launch_pairs_gemm<2>(nt, grid, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0);
-  else
-    launch_pairs_gemm<1>(nt, grid, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0);
+  launch_pairs_gemm<1>(nt, grid, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0);
   return check_launch("ftx_spconv_pairs_gemm");
 }
 
@@ -470,13 +402,7 @@ extern "C" int ftx_spconv_pairs_gemm_scatter(const float *A, int64_t rows_a, con
   hipStream_t st = (hipStream_t)stream;
   const int nt = gemm_nt(co);
   dim3 grid((unsigned)(ceil_div(n_pairs, TILE_P) + kvol), (unsigned)ceil_div(co, 32 * nt));
-  if (split_on())
-    split::launch(nt, grid, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, out, nullptr, 0, scatter, rows_out);
-  else if (gemm_use_pc(n_pairs, ca, co, nt))
-    FTX_REQUIRE(pc::dispatch(nt, pc_blocks(), st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, out, nullptr, 0, scatter, rows_out) == 0,
-                "ftx_spconv_pairs_gemm_scatter: could not configure the producer / consumer kernel");
-  else
-    launch_pairs_gemm<1>(nt, grid, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, out, nullptr, 0, scatter, rows_out);
+  launch_pairs_gemm<1>(nt, grid, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, out, nullptr, 0, scatter, rows_out);
   return check_launch("ftx_spconv_pairs_gemm_scatter");
 }
 
@@ -490,18 +416,9 @@ extern "C" int ftx_rows_gemm(const float *A, int64_t n, const float *W, int32_t 
   if (n == 0) return FTX_OK;
   FTX_REQUIRE(A && W && out, "ftx_rows_gemm: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  const int nt = gemm_nt(co), rt = gemm_rt(n, 1, ca, co);
-  dim3 grid((unsigned)ceil_div(n, TILE_P * rt), (unsigned)ceil_div(co, 32 * nt));
-  if (split_on()) {
-    dim3 g1((unsigned)ceil_div(n, TILE_P), grid.y);
-    split::launch(nt, g1, st, A, n, nullptr, W, w_transposed, nullptr, ca, co, 1, out, bias, n, nullptr, 0);
-  } else if (rt == 1 && gemm_use_dma(n, ca, co, nt)) {
-    FTX_REQUIRE(dma::dispatch(nt, grid, st, A, n, nullptr, W, w_transposed, nullptr, ca, co, 1, out, bias, n) == 0,
-                "ftx_rows_gemm: could not configure the LDS-DMA kernel");
-  } else if (rt == 2)
-    launch_pairs_gemm<2>(nt, grid, st, A, n, nullptr, W, w_transposed, nullptr, ca, co, 1, out, bias, n);
-  else
-    launch_pairs_gemm<1>(nt, grid, st, A, n, nullptr, W, w_transposed, nullptr, ca, co, 1, out, bias, n);
+  const int nt = gemm_nt(co);
+  dim3 grid((unsigned)ceil_div(n, TILE_P), (unsigned)ceil_div(co, 32 * nt));
+  launch_pairs_gemm<1>(nt, grid, st, A, n, nullptr, W, w_transposed, nullptr, ca, co, 1, out, bias, n);
   return check_launch("ftx_rows_gemm");
 }
 
@@ -975,49 +892,39 @@ static WgradCfg wgrad_config(int ca, int cg) {
   else if (cg % 96 == 0 && cg % 128 != 0) { c.ni = 3; c.wng = 1; }
   else { c.ni = 2; c.wng = 2; }
   // a 96 x 96 tile per wave is 9 accumulators (144 registers): one wave per SIMD.  96 -> 96 layers take a 128 x 96 tile instead
-  // (2 x 3 accumulators per wave, the last 32 M rows are padding); FTX_WGRAD_M96=1 selects the 96 x 96 form for measurements.
-  static const int m96 = getenv("FTX_WGRAD_M96") ? atoi(getenv("FTX_WGRAD_M96")) : 0;
-  if (c.mi == 3 && c.ni == 3 && !m96) { c.mi = 2; c.wmg = 2; }
+  // (2 x 3 accumulators per wave, the last 32 M rows are padding).
+  if (c.mi == 3 && c.ni == 3) { c.mi = 2; c.wmg = 2; }
   return c;
 }
 
-// Resident blocks per CU of the instantiation a layer uses (registers / LDS decide: 2 for the 128-wide tiles, up to 8 for 32 x 32),
-// asked from the runtime once per instantiation; 2 when there is no device to ask (the workspace query on a CPU-only host).
-template <int MI, int NI, int WMG, int WNG>
-static int wgrad_occ_of() {
-  static int occ = 0;
-  if (occ == 0) {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pairs_wgrad_kernel<MI, NI, WMG, WNG>, 256, 0) != hipSuccess || n < 1) {
-      (void)hipGetLastError();
-      n = 2;
-    }
-    occ = n > 8 ? 8 : n;
-  }
-  return occ;
-}
-template <int MI, int WMG>
-static int wgrad_occ_n(const WgradCfg &c) {
-  if (c.ni == 1) return wgrad_occ_of<MI, 1, WMG, 1>();
-  if (c.ni == 3) return wgrad_occ_of<MI, 3, WMG, 1>();
-  if (c.wng == 1) return wgrad_occ_of<MI, 2, WMG, 1>();
-  return wgrad_occ_of<MI, 2, WMG, 2>();
-}
+// Resident blocks per CU of the instantiation a layer uses, as a TABLE: registers decide (a block is one wave per SIMD, a SIMD has 512
+// vector registers; LDS never binds first).  Values = min(8, 512 / allocated VGPRs) read from the gfx950 code object (llvm-readelf --notes:
+// .vgpr_count 60 / 96-104 / 128-136 / 156 / 184-236 / 316) -- tests/test_cabi.py recomputes them from the built object and fails when the
+// table is stale.  A table and not hipOccupancyMaxActiveBlocksPerMultiprocessor: the tile length, the workspace size and the summation tree
+// of the weight gradient (hence its bits) must be functions of the arguments alone, the same on every host and device (round 2 asked the
+// runtime, with a fallback of 2 where there was no device to ask).
 static int wgrad_occ(const WgradCfg &c) {
-  if (c.mi == 1) return wgrad_occ_n<1, 1>(c);
-  if (c.mi == 3) return wgrad_occ_n<3, 1>(c);
-  if (c.wmg == 1) return wgrad_occ_n<2, 1>(c);
-  return wgrad_occ_n<2, 2>(c);
+  // rows: M side (mi, wmg) = (1,1) (2,1) (3,1) (2,2); columns: N side (ni, wng) in the same order
+  static const int occ[4][4] = {{8, 4, 3, 3}, {5, 3, 2, 2}, {4, 2, 1, 2}, {3, 2, 2, 2}};
+  auto side = [](int i, int w) { return w == 2 ? 3 : i - 1; };
+  return occ[side(c.mi, c.wmg)][side(c.ni, c.wng)];
 }
+// (mi, wmg, ni, wng) -> table value, for the build-time check of the table against the code object
+extern "C" int32_t ftx_spconv_wgrad_table_blocks(int32_t mi, int32_t wmg, int32_t ni, int32_t wng) {
+  if (!((mi >= 1 && mi <= 3 && wmg == 1) || (mi == 2 && wmg == 2)) || !((ni >= 1 && ni <= 3 && wng == 1) || (ni == 2 && wng == 2))) return -1;
+  WgradCfg c{mi, wmg, ni, wng};
+  return wgrad_occ(c);
+}
+extern "C" int32_t ftx_spconv_wgrad_resident_blocks(int32_t ca, int32_t cg) { return wgrad_occ(wgrad_config(ca, cg)); }
+constexpr int WGRAD_CUS = 256;   // MI355X; a constant of the tiling, not a device query (see above)
 
 // Pairs per tile.  All blocks of a launch should be resident together: a launch of 1.2x the resident slots takes as long as one of 2x
 // (measured: 620 blocks on 512 slots ran 1.7x longer than 820).  So the tile length is chosen for R full rounds of
 // slots = CUs x resident blocks per CU, R as small as keeps a tile <= 4096 pairs; every offset adds about half a tile of rounding.
 static int wgrad_tile_len(int64_t n_pairs, int ca, int cg, int kvol) {
   const WgradCfg c = wgrad_config(ca, cg);
-  static const int forced = getenv("FTX_WGRAD_BLOCKS") ? atoi(getenv("FTX_WGRAD_BLOCKS")) : 0;
   const int64_t mn_tiles = ceil_div(ca, 32 * c.mi * c.wmg) * ceil_div(cg, 32 * c.ni * c.wng);
-  const int64_t slots = forced > 0 ? forced : (int64_t)device_cus() * wgrad_occ(c);
+  const int64_t slots = (int64_t)WGRAD_CUS * wgrad_occ(c);
   int64_t len = 256;
   for (int rounds = 1; rounds <= 64; ++rounds) {
     int64_t tiles = (slots * rounds * 15 / 16) / mn_tiles - (kvol + 1) / 2;   // 1/16 of head room: an overshoot costs a whole round

@@ -72,6 +72,39 @@ def _scratch(nbytes, like):
     return buf
 
 
+# The statistics kernels (BatchNorm, the convolution's reduce-with-statistics pass) keep a few ticket counters per (device, stream)
+# (include/ftx.h, ftx_stream_scratch_*).  The caller owns that buffer: it is a torch allocation attached to the stream at its first use.
+_TICKETS = {}
+
+
+def _stream_scratch(st=None):
+    """Make sure the current stream has its ticket buffer attached (a dict lookup after the first call); returns the raw stream."""
+    if st is None:
+        st = stream()
+    key = (torch.cuda.current_device(), st)
+    if key not in _TICKETS and not torch.cuda.is_current_stream_capturing():
+        L = _lib.load()
+        n = int(L.ftx_stream_scratch_bytes())
+        buf = torch.empty((n,), dtype=torch.uint8, device=torch.device("cuda", key[0]))
+        check(L.ftx_stream_scratch_attach(st, buf.data_ptr(), n), "ftx_stream_scratch_attach")
+        _TICKETS[key] = buf
+    return st
+
+
+def reset_stream_scratch():
+    """Clear the ticket counters of the current stream (after a kernel of the library died mid-flight on it)."""
+    check(_lib.load().ftx_stream_scratch_reset(stream()), "ftx_stream_scratch_reset")
+
+
+def release_stream_scratch():
+    """Detach (and free) the ticket buffers of every stream this process attached one to."""
+    L = _lib.load()
+    for (dev, st) in list(_TICKETS):
+        with torch.cuda.device(dev):
+            check(L.ftx_stream_scratch_release(st), "ftx_stream_scratch_release")
+        del _TICKETS[(dev, st)]
+
+
 # ---------------------------------------------------------------- integer side
 def sphash(coords: torch.Tensor, offsets: torch.Tensor | None = None) -> torch.Tensor:
     """spf.sphash: (N,4) int32 -> (N,) int64, or with (K,3) offsets -> (K,N)."""
@@ -591,7 +624,7 @@ class _BatchNormTrain(torch.autograd.Function):
         ws = _scratch(ws_bytes, x)
         _log_launch("bn_fwd", dict(n=n, c=c, reads=2 + (residual is not None), writes=1), lambda: check(L.ftx_bn_train_fwd(
             ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps),
-            n, c, int(relu), ptr(y), ptr(mean), ptr(invstd), ptr(ws), ws_bytes, stream()), "ftx_bn_train_fwd"))
+            n, c, int(relu), ptr(y), ptr(mean), ptr(invstd), ptr(ws), ws_bytes, _stream_scratch()), "ftx_bn_train_fwd"))
         ctx.save_for_backward(x, y, gamma, mean, invstd)
         ctx.relu = int(relu)
         ctx.has_res = residual is not None
@@ -642,7 +675,7 @@ def _bn_backward_launch(gy, x, y, gamma, mean, invstd, relu, has_res):
     # two passes (statistics, apply), each reading gy and x (and y for the ReLU mask); one or two row matrices written
     _log_launch("bn_bwd", dict(n=n, c=c, reads=2 * (2 + (1 if relu else 0)), writes=1 + (1 if has_res else 0)), lambda: check(L.ftx_bn_train_bwd(
         ptr(gy), ptr(x), ptr(y), ptr(gamma), ptr(mean), ptr(invstd), n, c, int(relu), ptr(gx), ptr(gres), ptr(ggamma),
-        ptr(gbeta), ptr(ws), ws_bytes, stream()), "ftx_bn_train_bwd"))
+        ptr(gbeta), ptr(ws), ws_bytes, _stream_scratch()), "ftx_bn_train_bwd"))
     return gx, gres, ggamma, gbeta
 
 
@@ -671,7 +704,7 @@ class _ConvBNTrain(torch.autograd.Function):
                 raise ValueError("conv_bn: BatchNorm parameter length != output channels")
         stats = _empty((2, co), F32, feats)              # row 0: batch mean, row 1: 1 / sqrt(var + eps)
         p_mean, p_invstd = stats.data_ptr(), stats.data_ptr() + 4 * co
-        st = stream()
+        st = _stream_scratch()
         direct = (transposed and km.fine_bijective) or n_out == 0 or km.n_pairs == 0
         if direct:
             x = _conv_forward(feats, kernel, km, transposed)
@@ -708,7 +741,7 @@ class _ConvBNTrain(torch.autograd.Function):
         n, co = x.shape
         kvol, ca, _ = kernel.shape
         need_feats, need_kernel = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        st = stream()
+        st = _stream_scratch()
         p_mean, p_invstd = stats.data_ptr(), stats.data_ptr() + 4 * co
         gparams = _empty((2, co), F32, x)               # row 0: d gamma, row 1: d beta
         gres = torch.empty_like(x) if ctx.has_res else None
@@ -947,7 +980,7 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------- ViT self-attention
 class _Attention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, scale):
+    def forward(ctx, qkv, scale, tiling=(0, 0)):
         L = _lib.load()
         qkv = req(qkv.contiguous(), F32, "attention qkv", 5)
         b, t, three, h, d = qkv.shape
@@ -955,10 +988,11 @@ class _Attention(torch.autograd.Function):
             raise ValueError(f"attention: qkv must be (B, T, 3, heads, 64), got {tuple(qkv.shape)}")
         out = _empty((b, t, h * d), F32, qkv)
         lse = _empty((b, h, t), F32, qkv)
-        _log_launch("attn_fwd", dict(b=b, t=t, h=h, d=d, products=2), lambda: check(L.ftx_attn_fwd(
-            ptr(qkv), b, t, h, d, float(scale), ptr(out), ptr(lse), stream()), "ftx_attn_fwd"))
+        qw, split = int(tiling[0]), int(tiling[1])
+        _log_launch("attn_fwd", dict(b=b, t=t, h=h, d=d, products=2), lambda: check(L.ftx_attn_fwd_tiled(
+            ptr(qkv), b, t, h, d, float(scale), ptr(out), ptr(lse), qw, split, stream()), "ftx_attn_fwd"))
         ctx.save_for_backward(qkv, out, lse)
-        ctx.scale = float(scale)
+        ctx.scale, ctx.tiling = float(scale), (qw, split)
         return out
 
     @staticmethod
@@ -970,14 +1004,15 @@ class _Attention(torch.autograd.Function):
         gqkv = torch.empty_like(qkv)
         ws_bytes = int(L.ftx_attn_bwd_workspace_bytes(b, t, h))
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=qkv.device)
-        _log_launch("attn_bwd", dict(b=b, t=t, h=h, d=d, products=7), lambda: check(L.ftx_attn_bwd(
-            ptr(qkv), ptr(out), ptr(go), ptr(lse), b, t, h, d, ctx.scale, ptr(gqkv), ptr(ws), ws_bytes, stream()), "ftx_attn_bwd"))
-        return gqkv, None
+        _log_launch("attn_bwd", dict(b=b, t=t, h=h, d=d, products=7), lambda: check(L.ftx_attn_bwd_tiled(
+            ptr(qkv), ptr(out), ptr(go), ptr(lse), b, t, h, d, ctx.scale, ptr(gqkv), ptr(ws), ws_bytes, ctx.tiling[0], ctx.tiling[1], stream()), "ftx_attn_bwd"))
+        return gqkv, None, None
 
 
-def attention(qkv, scale):
-    """softmax(Q K^T * scale) V for qkv (B, T, 3, heads, 64) -> (B, T, heads*64)."""
-    return _Attention.apply(qkv, scale)
+def attention(qkv, scale, tiling=(0, 0)):
+    """softmax(Q K^T * scale) V for qkv (B, T, 3, heads, 64) -> (B, T, heads*64).  `tiling` = (waves per block, key groups) of the
+    kernels, (0, 0) = chosen per launch (ftx_attn_fwd_tiled in include/ftx.h): a per-call argument for tests and tools."""
+    return _Attention.apply(qkv, scale, tiling)
 
 
 # ---------------------------------------------------------------- fused sample_down

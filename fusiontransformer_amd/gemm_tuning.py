@@ -36,17 +36,31 @@ def n_results() -> int:
     return len(tunable.get_results())
 
 
-def save(rank: int = 0) -> bool:
-    """Rank 0: copy this process's results over the shared file if it gained entries (best effort: a read-only
-    install simply keeps tuning at start-up)."""
-    if rank != 0 or _private is None or not os.path.exists(_private):
+def save(rank: int = 0, write_shared=None) -> bool:
+    """Rank 0: flush TunableOp's results to this process's private file and report whether it gained entries over the shared file.
+    The shared file is only REWRITTEN when asked to -- `write_shared=True`, or FTX_TUNABLEOP_WRITE=1, or FTX_TUNABLEOP_FILE names a file
+    of the caller's: the default shared file is a tracked source file inside the package, and a benchmark run must not edit the tree."""
+    if rank != 0 or _private is None:
         return False
+    try:
+        import torch.cuda.tunable as tunable
+        tunable.write_file(_private)        # TunableOp keeps new selections in memory until asked (or until exit)
+    except Exception:
+        pass
+    if not os.path.exists(_private):
+        return False
+    if write_shared is None:
+        write_shared = os.environ.get("FTX_TUNABLEOP_WRITE") == "1" or "FTX_TUNABLEOP_FILE" in os.environ
     try:
         new = open(_private).read()
         old = open(SHARED).read() if os.path.exists(SHARED) else ""
         if new.count("\n") > old.count("\n"):
-            shutil.copyfile(_private, SHARED)
-            return True
+            if write_shared:
+                shutil.copyfile(_private, SHARED)
+                return True
+            import sys
+            print("[fusiontransformer_amd] %d new library-GEMM selections were tuned in this process and not persisted (%s); set FTX_TUNABLEOP_WRITE=1 "
+                  "to update %s" % (new.count("\n") - old.count("\n"), _private, SHARED), file=sys.stderr, flush=True)
     except OSError:
         pass
     return False

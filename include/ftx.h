@@ -36,6 +36,19 @@ extern "C" {
 int ftx_version(void);
 const char *ftx_last_error(void);
 
+/* ---- per-(device, stream) ticket buffer of the statistics kernels (ftx_spconv_reduce_stats, ftx_bn_train_fwd / _bwd) ----
+ * Those kernels hand their column totals to "the last block to finish", which needs a few ticket counters and group rows that persist
+ * across the blocks of a launch (csrc/ftx_lastblock.h).  The caller owns them: allocate ftx_stream_scratch_bytes() bytes of device
+ * memory (256-byte aligned), attach them to the stream (the library zeroes the tickets on that stream) and keep them alive until
+ * ftx_stream_scratch_release(stream) or the end of the process.  A stream nobody attached a buffer to gets a library allocation at its
+ * first use (outside stream capture), freed by ftx_stream_scratch_release.  ftx_stream_scratch_reset zeroes the tickets on the stream:
+ * call it after a kernel of the library died mid-flight (a dirty ticket otherwise trips a device-side assert in the next launch).
+ * Keyed by (current device, stream).  No other state of the library outlives a call. */
+size_t ftx_stream_scratch_bytes(void);
+int ftx_stream_scratch_attach(void *stream, void *buffer, size_t bytes);
+int ftx_stream_scratch_reset(void *stream);
+int ftx_stream_scratch_release(void *stream);
+
 /* ---- coordinate hashing ------------------------------------------------ */
 
 /* spf.sphash(C): models/utils.py:19,49,79.  coords (n,4) int32 [x,y,z,b] -> out (n) int64. */
@@ -176,20 +189,6 @@ int ftx_spconv_pairs_gemm(const float *A, int64_t rows_a, const int32_t *gather,
  * named by scatter are left untouched.  Replaces pairs_gemm + reduce (no tmp round trip). */
 int ftx_spconv_pairs_gemm_scatter(const float *A, int64_t rows_a, const int32_t *gather, const int32_t *scatter, const float *W, int32_t w_transposed, const int32_t *koff, int64_t n_pairs, int32_t ca, int32_t co, int32_t kvol, float *out, int64_t rows_out, void *stream);
 
-/* Kernel variant of the pair GEMM (process-wide switch, initial value from FTX_GEMM_DMA=1 / FTX_GEMM_PC=1): 0 register-staged tile kernel
- * (default), 1 LDS-DMA tile kernel, 2 persistent producer / consumer kernel (loader waves fill an LDS ring ahead of the MFMA waves).
- * All three compute the same exact-f32 MFMA sequence: bit-identical results. */
-void ftx_spconv_set_gemm_variant(int32_t variant);
-int32_t ftx_spconv_get_gemm_variant(void);
-
-/* Arithmetic of the sparse-convolution matrix products (process-wide switch, initial value from FTX_SPCONV_SPLIT):
- *   0 (default)  exact-f32 MFMA (v_mfma_f32_32x32x2_f32): bit-for-bit an f32 fma chain;
- *   1            every f32 operand split in-kernel into three bf16 terms (exact), six bf16-MFMA partial products accumulated in
- *                f32: per-product error < 2^-24, i.e. f32-equivalent, at 2.67x less matrix-pipe time.  Deterministic, but not
- *                bit-identical to mode 0.  Affects ftx_spconv_pairs_gemm(_scatter), ftx_rows_gemm and ftx_spconv_pairs_wgrad. */
-void ftx_spconv_set_split(int32_t on);
-int32_t ftx_spconv_get_split(void);
-
 /* Dense rows on the same tile code: out[r,:] = A[r,:] @ W (+ bias), r < n.  W as above with kvol = 1;
  * bias (co) may be NULL.  Replaces the point-branch nn.Linear layers (models/spvcnn.py:164-180,
  * models/middle_fusion.py:18-29) and the kernel_size=1 spnn.Conv3d (spvcnn.py:71-75). */
@@ -202,7 +201,7 @@ int ftx_spconv_reduce(const float *tmp, const int32_t *pos, int64_t n, int32_t c
  * partial (sum, sum of squares) rows, nb = ftx_spconv_reduce_stats_blocks(n, co), then ONE row of column totals, summed in block
  * order by whichever block finishes last (no second launch; bit-reproducible).  Feed `part + nb*2*co` to
  * ftx_bn_train_fwd_totals: the Conv3d -> BatchNorm pair of every SPVCNN block (models/spvcnn.py:22-35,53-79) then reads the
- * convolution output once.  Uses a small per-stream ticket buffer owned by the library (allocated at first use on a stream). */
+ * convolution output once.  Uses the stream's ticket buffer (ftx_stream_scratch_* below). */
 int32_t ftx_spconv_reduce_stats_blocks(int64_t n, int32_t co);
 int ftx_spconv_reduce_stats(const float *tmp, const int32_t *pos, int64_t n, int32_t co, int32_t kvol, float *out, double *part, int32_t nb, void *stream);
 
@@ -210,6 +209,11 @@ int ftx_spconv_reduce_stats(const float *tmp, const int32_t *pos, int64_t n, int
  * idx_a = idx_g = koff = NULL with kvol = 1: dense rows, dW = A[:n_pairs]^T @ G[:n_pairs]. */
 size_t ftx_spconv_pairs_wgrad_workspace_bytes(int64_t n_pairs, int32_t ca, int32_t cg, int32_t kvol);
 int ftx_spconv_pairs_wgrad(const float *A, int64_t rows_a, const int32_t *idx_a, const float *G, int64_t rows_g, const int32_t *idx_g, const int32_t *koff, int64_t n_pairs, int32_t ca, int32_t cg, int32_t kvol, float *dW, void *workspace, size_t workspace_bytes, void *stream);
+/* Resident blocks per CU the weight-gradient tiling assumes for a (ca, cg) layer / for a kernel instantiation (mi, wmg, ni, wng): a
+ * constant table (csrc/ftx_spconv.hip), never a device query, so workspace size, tile length and summation order are functions of the
+ * arguments alone.  Exposed so that the build can check the table against the code object (tests/test_cabi.py). */
+int32_t ftx_spconv_wgrad_resident_blocks(int32_t ca, int32_t cg);
+int32_t ftx_spconv_wgrad_table_blocks(int32_t mi, int32_t wmg, int32_t ni, int32_t wng);
 
 /* ---- BatchNorm1d over rows (+residual, +ReLU): spnn.BatchNorm / nn.BatchNorm1d
  *      models/spvcnn.py:30-31,71-79,100-102,164-180; models/middle_fusion.py:18-22 */
@@ -267,10 +271,12 @@ int ftx_attn_fwd(const float *qkv, int32_t b, int32_t t, int32_t h, int32_t d, f
 /* grad_qkv (b, t, 3, h, d) fully written.  workspace: ftx_attn_bwd_workspace_bytes(b, t, h). */
 size_t ftx_attn_bwd_workspace_bytes(int32_t b, int32_t t, int32_t h);
 int ftx_attn_bwd(const float *qkv, const float *out, const float *grad_out, const float *lse, int32_t b, int32_t t, int32_t h, int32_t d, float scale, float *grad_qkv, void *workspace, size_t workspace_bytes, void *stream);
-/* Tiling of the three attention kernels: qw waves of 32 queries (keys) per block x split key (query) groups.  (0, 0) = chosen per launch
- * from b*h*ceil(t/32) against the device's SIMD count (default); built: (4,2) (2,2) (2,4) (1,2) (1,4) (1,8).  A measurement / test aid:
- * results of different tilings differ in the last bits (the key range is summed in a different grouping), never with timing. */
-int ftx_attn_set_config(int32_t qw, int32_t split);
+/* The same two calls with an explicit tiling of the three attention kernels: qw waves of 32 queries (keys) per block x split key (query)
+ * groups.  (0, 0) = chosen per launch from b*h*ceil(t/32) (what ftx_attn_fwd / ftx_attn_bwd do); built: (4,2) (2,2) (2,4) (1,2) (1,4) (1,8);
+ * anything else is refused.  A per-call argument, not a process-wide switch.  A measurement / test aid: results of different tilings
+ * differ in the last bits (the key range is summed in a different grouping), never with timing. */
+int ftx_attn_fwd_tiled(const float *qkv, int32_t b, int32_t t, int32_t h, int32_t d, float scale, float *out, float *lse, int32_t qw, int32_t split, void *stream);
+int ftx_attn_bwd_tiled(const float *qkv, const float *out, const float *grad_out, const float *lse, int32_t b, int32_t t, int32_t h, int32_t d, float scale, float *grad_qkv, void *workspace, size_t workspace_bytes, int32_t qw, int32_t split, void *stream);
 
 /* ---- fused train-step losses + metric: modules/SemanticTrainer.py:158-194, models/metric.py:37-58 ----
  * losses[0] = loss_2d = CE_w(img_logit) + lambda * KL(softmax(lidar_logit) || softmax(img_logit2))

@@ -264,52 +264,6 @@ def test_fused_conv_batchnorm_node_matches_oracle_ops(env, ca, co, ks, cur, s, t
     assert torch.equal(yg2, yg.detach())
 
 
-@pytest.mark.parametrize("ca,co,ks,cur,s", [(32, 32, 3, 1, 1), (128, 96, 3, 1, 1), (64, 64, 2, 1, 2), (384, 256, 3, 2, 1), (4, 32, 3, 1, 1), (96, 20, 3, 1, 1)])
-def test_split_bf16_arithmetic_is_f32_accurate(env, ca, co, ks, cur, s):
-    """The opt-in bf16x3 arithmetic of the sparse-conv matrix products (ftx_spconv_set_split(1): every f32 operand split exactly into
-    three bf16 terms, six bf16-MFMA partial products, f32 accumulate) is held to the SAME accuracy as the exact-f32 MFMA kernels:
-    forward, data gradient and weight gradient are compared with a float64 evaluation, and the split path's error may not exceed
-    1.5x the exact path's (+ one f32 ulp of the largest value).  Operands span 12 binary orders of magnitude."""
-    spf, O = env
-    from fusiontransformer_amd import _lib
-    from fusiontransformer_amd.sparse import CoordinateManager
-    L = _lib.load()
-    rng = np.random.default_rng(21)
-    c = random_coords(rng, 3000, extent=40, batch=2)
-    c = c[np.argsort(O.sphash(c))]
-    cm = CoordinateManager()
-    cm.coords[1] = dev(c)
-    st = 1
-    while st < cur:
-        cm.kernel_map(2, st, 2)
-        st *= 2
-    km = cm.kernel_map(ks, cur, s)
-    idx_query, _ = O.build_kernel_map(cm.coords[cur].cpu().numpy(), cur, ks, s)
-    x = (rng.standard_normal((km.n_in, ca)) * np.exp2(rng.integers(-6, 7, size=(km.n_in, 1)))).astype(np.float32)
-    w = (rng.standard_normal((ks ** 3, ca, co)) / np.sqrt(ca * ks ** 3)).astype(np.float32)
-    go = rng.standard_normal((km.n_out, co)).astype(np.float32)
-    xo, wo = torch.from_numpy(x).double().requires_grad_(True), torch.from_numpy(w).double().requires_grad_(True)
-    yo = O.sparseconv_op(xo, wo, idx_query, km.n_out, False)
-    yo.backward(torch.from_numpy(go).double())
-    res = {}
-    try:
-        for mode in (0, 1):
-            L.ftx_spconv_set_split(mode)
-            assert L.ftx_spconv_get_split() == mode
-            xg, wg = dev(x).requires_grad_(True), dev(w).requires_grad_(True)
-            yg = spf.sparse_conv(xg, wg, km, False)
-            yg.backward(dev(go))
-            res[mode] = [t.detach().cpu().double() for t in (yg, xg.grad, wg.grad)]
-    finally:
-        L.ftx_spconv_set_split(0)
-    for name, ref, exact, split in zip(("forward", "dgrad", "wgrad"), (yo.detach(), xo.grad, wo.grad), res[0], res[1]):
-        e_exact, e_split = (exact - ref).abs().max().item(), (split - ref).abs().max().item()
-        ulp = ref.abs().max().item() * 2.0 ** -23
-        assert e_split <= 1.5 * e_exact + ulp, (name, e_exact, e_split)
-        assert (split - ref).norm().item() <= 1.5 * (exact - ref).norm().item() + 1e-12, name
-    assert not torch.equal(res[0][0], res[1][0]) or ca <= 4   # the switch really selects another kernel
-
-
 @pytest.mark.parametrize("n,ca,co", [(5000, 32, 256), (3001, 256, 128), (777, 96, 20), (4096, 128, 96), (130, 4, 32), (1, 384, 256)])
 def test_rows_linear_and_matmul_match_torch(env, n, ca, co):
     spf, O = env
@@ -599,23 +553,20 @@ def test_attention_every_tiling(env, cfg):
     spf, O = env
     L = spf._lib.load()
     rng = np.random.default_rng(13)
-    try:
-        assert L.ftx_attn_set_config(*cfg) == 0
-        for B, T, H in [(1, 70, 2), (1, 578, 3)]:
-            qkv = rng.standard_normal((B, T, 3, H, 64)).astype(np.float32)
-            go = rng.standard_normal((B, T, H * 64)).astype(np.float32)
-            r = torch.from_numpy(qkv).double().requires_grad_(True)
-            q, k, v = r.permute(2, 0, 3, 1, 4)
-            ref = (((q @ k.transpose(-2, -1)) * 0.125).softmax(dim=-1) @ v).transpose(1, 2).reshape(B, T, H * 64)
-            ref.backward(torch.from_numpy(go).double())
-            x = dev(qkv).requires_grad_(True)
-            out = spf.attention(x, 0.125)
-            out.backward(dev(go))
-            np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=2e-6)
-            np.testing.assert_allclose(x.grad.cpu().numpy(), r.grad.numpy(), rtol=1e-3, atol=2e-5)
-    finally:
-        L.ftx_attn_set_config(0, 0)
-    assert L.ftx_attn_set_config(3, 2) != 0      # not a built tiling: refused, nothing changes
+    for B, T, H in [(1, 70, 2), (1, 578, 3)]:
+        qkv = rng.standard_normal((B, T, 3, H, 64)).astype(np.float32)
+        go = rng.standard_normal((B, T, H * 64)).astype(np.float32)
+        r = torch.from_numpy(qkv).double().requires_grad_(True)
+        q, k, v = r.permute(2, 0, 3, 1, 4)
+        ref = (((q @ k.transpose(-2, -1)) * 0.125).softmax(dim=-1) @ v).transpose(1, 2).reshape(B, T, H * 64)
+        ref.backward(torch.from_numpy(go).double())
+        x = dev(qkv).requires_grad_(True)
+        out = spf.attention(x, 0.125, tiling=cfg)      # the tiling is an argument of the call: no process-wide switch
+        out.backward(dev(go))
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(x.grad.cpu().numpy(), r.grad.numpy(), rtol=1e-3, atol=2e-5)
+    with pytest.raises(RuntimeError):
+        spf.attention(dev(rng.standard_normal((1, 70, 3, 2, 64)).astype(np.float32)), 0.125, tiling=(3, 2))      # not a built tiling: refused
 
 
 def test_attention_large_logits_are_stable(env):
@@ -751,105 +702,6 @@ def test_batch_with_an_empty_frame_and_far_coordinates(env):
         assert np.array_equal(ci[nbr[kk, oo], 3], co[oo, 3])
 
 
-def test_lds_dma_gemm_variant_matches_the_default_kernel(env):
-    """The opt-in LDS-DMA pair GEMM (FTX_GEMM_DMA=1, csrc/ftx_spconv_dma.h) against the default register-staged kernel:
-    same tiles, same MFMA order, so the results are bit-identical -- forward and transposed weights, full and ragged
-    tiles, dense rows with bias.  Run in a child process because the switch is read once per process."""
-    import subprocess, sys, textwrap
-    code = textwrap.dedent("""
-        import os, sys, torch
-        sys.path.insert(0, %r)
-        from fusiontransformer_amd import functional as spf
-        from fusiontransformer_amd.data.synth import make_batch
-        from fusiontransformer_amd.models.utils import initial_voxelize
-        from fusiontransformer_amd.sparse import PointTensor
-        torch.manual_seed(0)
-        b = make_batch([0, 1], max_points=6000)
-        z = PointTensor(torch.from_numpy(b["feats"]).cuda(), torch.from_numpy(b["coords"]).float().cuda())
-        cm = initial_voxelize(z, 1, 1).cm
-        L = spf._lib.load()
-        outs = []
-        for ks, s, st, ca, co in [(3, 1, 1, 32, 32), (3, 1, 1, 128, 96), (3, 1, 1, 64, 128), (2, 1, 2, 32, 64), (3, 2, 1, 96, 256)]:
-            km = cm.kernel_map(ks, s, st)
-            A = torch.randn(km.n_in, ca, device="cuda")
-            for wt in (0, 1):
-                W = torch.randn(ks ** 3, *((co, ca) if wt else (ca, co)), device="cuda") * 0.1
-                tmp = torch.zeros(km.n_pairs, co, device="cuda")
-                rc = L.ftx_spconv_pairs_gemm(A.data_ptr(), km.n_in, km.pair_in.data_ptr(), W.data_ptr(), wt, km.koff.data_ptr(), km.n_pairs, ca, co, ks ** 3, tmp.data_ptr(), spf.stream())
-                assert rc == 0
-                outs.append(tmp.cpu())
-        x = torch.randn(1000, 64, device="cuda"); w = torch.randn(96, 64, device="cuda"); bias = torch.randn(96, device="cuda")
-        outs.append(spf.linear(x, w, bias).cpu())
-        torch.save(outs, sys.argv[1])
-    """) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    import tempfile
-    res = {}
-    with tempfile.TemporaryDirectory() as d:
-        for flag in ("0", "1"):
-            out = os.path.join(d, "o%s.pt" % flag)
-            subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, FTX_GEMM_DMA=flag), timeout=300)
-            res[flag] = torch.load(out, weights_only=True)
-    assert len(res["0"]) == len(res["1"]) == 11
-    for a, b in zip(res["0"], res["1"]):
-        assert torch.equal(a, b)
-
-
-def test_producer_consumer_gemm_variant_is_bit_identical(env):
-    """ftx_spconv_set_gemm_variant(2): the persistent producer / consumer pair GEMM (loader waves fill an LDS ring, two groups of MFMA
-    waves alternate over the workgroup's tiles, slot hand-over by FULL / FREE counters in LDS) against the default tile kernel: same
-    MFMA sequence per tile, so bit-identical -- forward and data-gradient weight layouts, ragged last tiles, tiny maps (fewer tiles than
-    workgroups), 1 / 4 / 8 / 12 chunks per tile, two column tiles, the scatter epilogue, whole model layers at the bench's size."""
-    spf, O = env
-    from fusiontransformer_amd import _lib
-    from fusiontransformer_amd.data.synth import make_batch
-    from fusiontransformer_amd.models.utils import initial_voxelize
-    from fusiontransformer_amd.sparse import PointTensor
-    L = _lib.load()
-    torch.manual_seed(0)
-    b = make_batch([0, 1], max_points=9000)
-    z = PointTensor(torch.from_numpy(b["feats"]).cuda(), torch.from_numpy(b["coords"]).float().cuda())
-    cm = initial_voxelize(z, 1, 1).cm
-    cases = [(3, 1, 1, 32, 32), (3, 1, 1, 128, 96), (3, 1, 1, 64, 128), (2, 1, 2, 32, 64), (3, 2, 1, 96, 256), (3, 2, 1, 384, 256), (3, 4, 1, 256, 256),
-             (2, 4, 2, 128, 128), (3, 16, 1, 256, 256)]
-    for s_ in (1, 2, 4, 8):          # walk down: every level's coordinates come from the strided map above it
-        cm.kernel_map(2, s_, 2)
-    try:
-        for ks, cur, st, ca, co in cases:
-            km = cm.kernel_map(ks, cur, st)
-            A = torch.randn(km.n_in, ca, device="cuda")
-            for wt in (0, 1):
-                W = torch.randn(ks ** 3, *((co, ca) if wt else (ca, co)), device="cuda") * 0.1
-                outs = []
-                for variant in (0, 2):
-                    L.ftx_spconv_set_gemm_variant(variant)
-                    assert L.ftx_spconv_get_gemm_variant() == variant
-                    tmp = torch.full((km.n_pairs, co), float("nan"), device="cuda")
-                    rc = L.ftx_spconv_pairs_gemm(A.data_ptr(), km.n_in, km.pair_in.data_ptr(), W.data_ptr(), wt, km.koff.data_ptr(), km.n_pairs, ca, co,
-                                                 ks ** 3, tmp.data_ptr(), spf.stream())
-                    assert rc == 0
-                    outs.append(tmp)
-                torch.cuda.synchronize()
-                assert torch.equal(outs[0], outs[1]), (ks, cur, st, ca, co, wt)
-            if ks == 2:   # scatter epilogue: data gradient of the strided conv
-                G = torch.randn(km.n_out, co, device="cuda")
-                Wt = torch.randn(8, ca, co, device="cuda") * 0.1
-                outs = []
-                for variant in (0, 2):
-                    L.ftx_spconv_set_gemm_variant(variant)
-                    outs.append(spf._spconv_direct(G, Wt, km.pair_out, km.pair_in, km.koff, km.n_pairs, km.n_in, ca, 1))
-                assert torch.equal(outs[0], outs[1])
-        # repeated launches reuse nothing across calls (the ring counters start at zero in every launch)
-        L.ftx_spconv_set_gemm_variant(2)
-        km = cm.kernel_map(3, 1, 1)
-        A = torch.randn(km.n_in, 64, device="cuda"); W = torch.randn(27, 64, 64, device="cuda")
-        t1 = torch.empty(km.n_pairs, 64, device="cuda"); t2 = torch.empty_like(t1)
-        for t in (t1, t2):
-            L.ftx_spconv_pairs_gemm(A.data_ptr(), km.n_in, km.pair_in.data_ptr(), W.data_ptr(), 0, km.koff.data_ptr(), km.n_pairs, 64, 64, 27, t.data_ptr(), spf.stream())
-        assert torch.equal(t1, t2)
-    finally:
-        L.ftx_spconv_set_gemm_variant(0)
-
-
 def test_round2_entry_points_edge_cases(env):
     """ftx_sorted_rank (absent keys, empty inputs, device-side count smaller than the buffer), the scatter epilogue on a map with a
     single pair and with a bad scatter index, reduce-with-statistics on one row, and bad arguments failing loudly."""
@@ -912,3 +764,36 @@ def test_round2_entry_points_edge_cases(env):
     # the fused loss refuses an unknown mix
     with pytest.raises(ValueError):
         spf.fusion_loss({}, torch.zeros(1), None, 0.1, False, mix="other")
+
+
+def test_stream_scratch_is_owned_by_the_caller(env):
+    """The ticket buffer of the statistics kernels is a torch allocation attached per (device, stream) (include/ftx.h ftx_stream_scratch_*):
+    dirtied tickets are cleared by reset, a second stream gets its own buffer, release detaches everything and the next call re-attaches."""
+    spf, O = env
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(48 * 40 + 3, 64, device="cuda", generator=g)
+    gamma, beta = torch.rand(64, device="cuda", generator=g) + 0.5, torch.randn(64, device="cuda", generator=g)
+
+    def bn():
+        rm, rv = torch.zeros(64, device="cuda"), torch.ones(64, device="cuda")
+        return spf.batch_norm(x, gamma, beta, rm, rv, True, relu=True)
+
+    y = bn()
+    key = (torch.cuda.current_device(), spf.stream())
+    assert key in spf._TICKETS and spf._TICKETS[key].numel() == spf._lib.load().ftx_stream_scratch_bytes()
+    spf._TICKETS[key][:256].fill_(0)          # what a reset must leave behind ...
+    torch.cuda.synchronize()
+    spf._TICKETS[key][4:8].fill_(1)           # ... after a kernel died with a ticket taken (group 0's counter = 0x01010101)
+    spf.reset_stream_scratch()
+    assert torch.equal(bn(), y)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        y_side = bn()
+        assert (torch.cuda.current_device(), spf.stream()) in spf._TICKETS
+    side.synchronize()
+    assert torch.equal(y_side, y) and len(spf._TICKETS) >= 2
+    torch.cuda.synchronize()
+    spf.release_stream_scratch()
+    assert not spf._TICKETS
+    assert torch.equal(bn(), y) and key in spf._TICKETS

@@ -37,12 +37,10 @@ for B in [int(x) for x in args.batches.split(",")]:
     flop_f = 4.0 * B * H * T * T * 64
     ref = None
     for qw, sp in CFGS:
-        assert L.ftx_attn_set_config(qw, sp) == 0
-        f = lambda: L.ftx_attn_fwd(qkv.data_ptr(), B, T, H, 64, 0.125, out.data_ptr(), lse.data_ptr(), spf.stream())
-        bw = lambda: L.ftx_attn_bwd(qkv.data_ptr(), out.data_ptr(), go.data_ptr(), lse.data_ptr(), B, T, H, 64, 0.125, gq.data_ptr(), ws.data_ptr(), ws_bytes, spf.stream())
+        f = lambda: L.ftx_attn_fwd_tiled(qkv.data_ptr(), B, T, H, 64, 0.125, out.data_ptr(), lse.data_ptr(), qw, sp, spf.stream())
+        bw = lambda: L.ftx_attn_bwd_tiled(qkv.data_ptr(), out.data_ptr(), go.data_ptr(), lse.data_ptr(), B, T, H, 64, 0.125, gq.data_ptr(), ws.data_ptr(), ws_bytes, qw, sp, spf.stream())
         tf = timeit(f); tb = timeit(bw)
         if (qw, sp) == (4, 2):
             ref = (out.clone(), gq.clone())
         d = "" if ref is None else "%.2e %.2e" % ((out - ref[0]).abs().max().item(), (gq - ref[1]).abs().max().item())
         print("%5d %8s | %9.1f %9.1f | %9.1f %9.1f | %s" % (B, "auto" if qw == 0 else "(%d,%d)" % (qw, sp), tf, flop_f / tf / 1e6, tb, 2.5 * flop_f / tb / 1e6, d))
-L.ftx_attn_set_config(0, 0)

@@ -11,14 +11,8 @@ from fusiontransformer_amd.sparse import PointTensor
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=4); ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--filter", default="", help="only layers whose name contains one of these comma-separated substrings")
 ap.add_argument("--what", default="gemm,reduce,wgrad", help="kernels to run (profiling runs: --what wgrad --iters 1)")
-ap.add_argument("--variant", type=int, default=0, help="pair-GEMM kernel variant: 0 tile kernel, 1 LDS-DMA tile kernel, 2 producer / consumer kernel")
-ap.add_argument("--split", action="store_true", help="bf16x3 split arithmetic (f32-equivalent) instead of the exact-f32 MFMA kernels")
 args = ap.parse_args()
 WHAT = set(args.what.split(","))
-if args.split:
-    spf._lib.load().ftx_spconv_set_split(1)
-if args.variant:
-    spf._lib.load().ftx_spconv_set_gemm_variant(args.variant)
 b = make_batch(list(range(args.batch)))
 z = PointTensor(torch.from_numpy(b["feats"]).cuda(), torch.from_numpy(b["coords"]).float().cuda())
 x0 = initial_voxelize(z, 1, 1)
