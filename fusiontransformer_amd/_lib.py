@@ -60,6 +60,9 @@ SIGNATURES = {
     "ftx_sample_down_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ftx_spconv_pairs_gemm": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "ftx_spconv_pairs_gemm_scatter": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
+    "ftx_spconv_ostat_supported": (_i32, [_i32, _i32, _i32, _i32]),
+    "ftx_spconv_ostat_blocks": (_i32, [_i64]),
+    "ftx_spconv_ostat": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "ftx_rows_gemm": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "ftx_spconv_reduce": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "ftx_spconv_reduce_stats_blocks": (_i32, [_i64, _i32]),

@@ -440,6 +440,37 @@ def _spconv_direct(A, W, gather, scatter, koff, n_pairs, n_rows_out, co, w_trans
     return out
 
 
+_OSTAT = os.environ.get("FTX_OSTAT", "1") != "0"      # A/B aid: 0 = every convolution on the pair-list kernels
+_OSTAT_OK = {}
+
+
+def ostat_supported(ca, co, kvol, w_transposed=False):
+    """Does the one-launch output-stationary kernel (ftx_spconv_ostat) take this layer?  (ca in {4, 32, 64}, co in {32, 64})"""
+    key = (int(ca), int(co), int(kvol), bool(w_transposed))
+    v = _OSTAT_OK.get(key)
+    if v is None:
+        v = _OSTAT_OK[key] = bool(_lib.load().ftx_spconv_ostat_supported(key[0], key[1], key[2], int(key[3])))
+    return v and _OSTAT
+
+
+def _spconv_ostat(A, W, nbr, n_rows_out, co, w_transposed, flip, part=0, nb=0, pairs=0):
+    """out[o] = sum_k A[nbr[k, o]] @ W[k] in ONE launch (no pair rows, no reduce pass); `part`: also the BatchNorm statistics."""
+    L = _lib.load()
+    rows_a, ca = A.shape
+    kvol = nbr.shape[0]
+    if nbr.shape[1] != n_rows_out:
+        raise ValueError("ostat sparse conv: the neighbour table does not match the output rows")
+    out = _empty((n_rows_out, co), F32, A)
+    st = _stream_scratch() if part else stream()
+
+    def launch():
+        check(L.ftx_spconv_ostat(ptr(A), rows_a, ptr(nbr), n_rows_out, ptr(W), int(w_transposed), int(flip), ca, co, kvol, ptr(out), part, nb, st),
+              "ftx_spconv_ostat")
+
+    _log_launch("spconv_ostat", dict(pairs=pairs, n_out=n_rows_out, ca=ca, co=co, kvol=kvol, direct=True), launch)
+    return out
+
+
 def _spconv_wgrad(A, idx_a, G, idx_g, koff, n_pairs):
     L = _lib.load()
     rows_a, ca = A.shape
@@ -470,6 +501,8 @@ def _conv_forward(feats, kernel, km, transposed):
     if transposed and km.fine_bijective:
         # every fine row is the destination of exactly one pair: the GEMM epilogue writes `out` itself
         return _spconv_direct(feats, kernel, km.pair_out, km.pair_in, km.koff, km.n_pairs, n_out, co, 0)
+    if not transposed and n_out > 0 and km.n_pairs > 0 and ostat_supported(ca, co, kvol):
+        return _spconv_ostat(feats, kernel, km.nbr, n_out, co, 0, 0, pairs=km.n_pairs)
     gather, pos = (km.pair_out, km.pos_t) if transposed else (km.pair_in, km.pos)
     return _spconv_apply(feats, kernel, gather, pos, km.koff, km.n_pairs, n_out, co, 0)
 
@@ -481,6 +514,9 @@ def _conv_backward(feats, kernel, km, transposed, grad_out, need_feats, need_ker
     if need_feats:
         if not transposed and km.fine_bijective:
             g_feats = _spconv_direct(grad_out, kernel, km.pair_out, km.pair_in, km.koff, km.n_pairs, feats.shape[0], ca, 1)
+        elif not transposed and km.submanifold and km.n_pairs > 0 and ostat_supported(co, ca, kvol, True):
+            # symmetric map: the data gradient is the same output-stationary kernel on the same table, read mirrored
+            g_feats = _spconv_ostat(grad_out, kernel, km.nbr, feats.shape[0], ca, 1, 1, pairs=km.n_pairs)
         else:
             pos_in = km.pos if transposed else km.pos_t
             g_feats = _spconv_apply(grad_out, kernel, out_side, pos_in, km.koff, km.n_pairs, feats.shape[0], ca, 1)
@@ -714,6 +750,15 @@ class _ConvBNTrain(torch.autograd.Function):
             _log_launch("bn_fwd", dict(n=n_out, c=co, reads=2 + (residual is not None), writes=1), lambda: check(L.ftx_bn_train_fwd(
                 ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps),
                 n_out, co, int(relu), ptr(y), p_mean, p_invstd, ws, ws_bytes, st), "ftx_bn_train_fwd"))
+        elif not transposed and ostat_supported(ca, co, kvol):
+            # thin layer: convolution + statistics in one launch, then the apply pass
+            nb = _ws_bytes("ftx_spconv_ostat_blocks", n_out)
+            part, = _carve(feats, 16 * (nb + 1) * co)
+            x = _spconv_ostat(feats, kernel, km.nbr, n_out, co, 0, 0, part=part, nb=nb, pairs=km.n_pairs)
+            y = torch.empty_like(x)
+            _log_launch("bn_fwd", dict(n=n_out, c=co, reads=1 + (residual is not None), writes=1), lambda: check(L.ftx_bn_train_fwd_totals(
+                ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum),
+                float(eps), n_out, co, int(relu), ptr(y), p_mean, p_invstd, part + 16 * nb * co, st), "ftx_bn_train_fwd_totals"))
         else:
             gather, pos = (km.pair_out, km.pos_t) if transposed else (km.pair_in, km.pos)
             x = _empty((n_out, co), F32, feats)
@@ -748,9 +793,10 @@ class _ConvBNTrain(torch.autograd.Function):
         bn_ws_bytes = _ws_bytes("ftx_bn_workspace_bytes", n, co)
         in_side, out_side = (km.pair_out, km.pair_in) if transposed else (km.pair_in, km.pair_out)
         direct = need_feats and (not transposed) and km.fine_bijective
+        ostat = need_feats and (not direct) and (not transposed) and km.submanifold and km.n_pairs > 0 and ostat_supported(co, ca, kvol, True)
         n_feats = feats.shape[0]
         wg_bytes = _ws_bytes("ftx_spconv_pairs_wgrad_workspace_bytes", km.n_pairs, ca, co, kvol) if (need_kernel and km.n_pairs > 0) else 0
-        tmp_bytes = 4 * km.n_pairs * ca if (need_feats and not direct) else 0
+        tmp_bytes = 4 * km.n_pairs * ca if (need_feats and not direct and not ostat) else 0
         bn_ws, gx, tmp, wg_ws = _carve(x, bn_ws_bytes, 4 * n * co, tmp_bytes, wg_bytes)
         # BatchNorm half: gx = d loss / d (convolution output) stays in the scratch buffer, it is consumed by the two calls below
         _log_launch("bn_bwd", dict(n=n, c=co, reads=2 * (2 + (1 if ctx.relu else 0)), writes=1 + (1 if ctx.has_res else 0)), lambda: check(L.ftx_bn_train_bwd(
@@ -766,6 +812,9 @@ class _ConvBNTrain(torch.autograd.Function):
                 _log_launch("spconv_pairs_gemm", dict(meta, direct=True), lambda: check(L.ftx_spconv_pairs_gemm_scatter(
                     gx, n, ptr(km.pair_out), ptr(km.pair_in), ptr(kernel), 1, ptr(km.koff), km.n_pairs, co, ca, kvol, ptr(g_feats), n_feats, st),
                     "ftx_spconv_pairs_gemm_scatter"))
+            elif ostat:
+                _log_launch("spconv_ostat", dict(meta, direct=True), lambda: check(L.ftx_spconv_ostat(
+                    gx, n, ptr(km.nbr), n_feats, ptr(kernel), 1, 1, co, ca, kvol, ptr(g_feats), 0, 0, st), "ftx_spconv_ostat"))
             else:
                 pos_in = km.pos if transposed else km.pos_t
                 _log_launch("spconv_pairs_gemm", meta, lambda: check(L.ftx_spconv_pairs_gemm(

@@ -22,14 +22,16 @@ from . import functional as Fn
 
 class KernelMap:
     """Pair list of one (kernel size, input stride, stride) map: see csrc/ftx_spconv.hip."""
-    __slots__ = ("nbr", "pos", "pos_t", "pair_in", "pair_out", "koff", "n_pairs", "n_in", "n_out", "out_coords", "kvol", "fine_bijective")
+    __slots__ = ("nbr", "pos", "pos_t", "pair_in", "pair_out", "koff", "n_pairs", "n_in", "n_out", "out_coords", "kvol", "fine_bijective", "submanifold")
 
-    def __init__(self, nbr, pos, pos_t, pair_in, pair_out, koff, n_pairs, n_in, n_out, out_coords, fine_bijective=False):
+    def __init__(self, nbr, pos, pos_t, pair_in, pair_out, koff, n_pairs, n_in, n_out, out_coords, fine_bijective=False, submanifold=False):
         self.nbr, self.pos, self.pos_t, self.pair_in, self.pair_out, self.koff = nbr, pos, pos_t, pair_in, pair_out, koff
         self.n_pairs, self.n_in, self.n_out, self.out_coords = n_pairs, n_in, n_out, out_coords
         self.kvol = nbr.shape[0]
         # strided 2^3 map: every input (fine) voxel has exactly one (parent, offset), so pair_in is a permutation of the fine rows
         self.fine_bijective = bool(fine_bijective) and n_pairs == n_in
+        # stride-1 odd kernel on one coordinate set: nbr[k, o] = i <=> nbr[K-1-k, i] = o, so the data gradient can read the same table mirrored
+        self.submanifold = bool(submanifold) and n_in == n_out and self.kvol % 2 == 1
 
 
 class CoordinateManager:
@@ -96,7 +98,7 @@ class CoordinateManager:
         pos, pos_t, pair_in, pair_out = Fn.kernel_map_pairs(nbr, pos, n_in, n_pairs)
         ks, cur_stride, stride = key
         km = KernelMap(nbr, pos, pos_t, pair_in, pair_out, koff, n_pairs, n_in, out_coords.shape[0], out_coords,
-                       fine_bijective=(ks == stride == 2))
+                       fine_bijective=(ks == stride == 2), submanifold=(stride == 1 and ks % 2 == 1))
         self.kernel_maps[key] = km
         return km
 

@@ -189,6 +189,19 @@ int ftx_spconv_pairs_gemm(const float *A, int64_t rows_a, const int32_t *gather,
  * named by scatter are left untouched.  Replaces pairs_gemm + reduce (no tmp round trip). */
 int ftx_spconv_pairs_gemm_scatter(const float *A, int64_t rows_a, const int32_t *gather, const int32_t *scatter, const float *W, int32_t w_transposed, const int32_t *koff, int64_t n_pairs, int32_t ca, int32_t co, int32_t kvol, float *out, int64_t rows_out, void *stream);
 
+/* Output-stationary convolution for thin layers, ONE launch (csrc/ftx_spconv_ostat.hip): out[o,:] = sum over k (ascending) of
+ * A[nbr[k,o],:] @ W[k], with nbr (kvol, n_out) int32 the neighbour table of the map (-1 = absent; what ftx_kernel_map_build returns).
+ * No pair-row scratch and no reduce pass; bit-identical to ftx_spconv_pairs_gemm + ftx_spconv_reduce on the pair list of the same
+ * table.  Replaces the Conv3d of models/spvcnn.py:22-35,98-126 where ftx_spconv_ostat_supported(ca, co, kvol, w_transposed) != 0
+ * (ca in {4, 32, 64}, co in {32, 64}).  W (kvol, ca, co), or (kvol, co, ca) when w_transposed.
+ * flip != 0: the data gradient of a submanifold convolution on the SAME table (symmetric map, odd kvol): out[i,:] = sum over k of
+ * A[nbr[kvol-1-k, i],:] @ W[k] -- pass the output gradient as A, w_transposed = 1 and the forward kernel as W.
+ * part != NULL: also the BatchNorm statistics of `out` as ftx_spconv_reduce_stats leaves them -- nb = ftx_spconv_ostat_blocks(n_out)
+ * partial rows [nb][2][co] float64 followed by the totals row [2][co] (read by ftx_bn_train_fwd_totals); uses the stream's ticket buffer. */
+int32_t ftx_spconv_ostat_supported(int32_t ca, int32_t co, int32_t kvol, int32_t w_transposed);
+int32_t ftx_spconv_ostat_blocks(int64_t n_out);
+int ftx_spconv_ostat(const float *A, int64_t rows_a, const int32_t *nbr, int64_t n_out, const float *W, int32_t w_transposed, int32_t flip, int32_t ca, int32_t co, int32_t kvol, float *out, double *part, int32_t nb, void *stream);
+
 /* Dense rows on the same tile code: out[r,:] = A[r,:] @ W (+ bias), r < n.  W as above with kvol = 1;
  * bias (co) may be NULL.  Replaces the point-branch nn.Linear layers (models/spvcnn.py:164-180,
  * models/middle_fusion.py:18-29) and the kernel_size=1 spnn.Conv3d (spvcnn.py:71-75). */

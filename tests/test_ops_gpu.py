@@ -797,3 +797,47 @@ def test_stream_scratch_is_owned_by_the_caller(env):
     spf.release_stream_scratch()
     assert not spf._TICKETS
     assert torch.equal(bn(), y) and key in spf._TICKETS
+
+
+@pytest.mark.parametrize("ca,co,ks,cur,s,n", [(4, 32, 3, 1, 1, 5003), (32, 32, 3, 1, 1, 5003), (32, 64, 3, 2, 1, 4000), (64, 64, 3, 1, 1, 3001), (64, 32, 3, 1, 1, 700),
+                                             (32, 32, 2, 1, 2, 5003), (64, 64, 2, 2, 2, 6000), (32, 32, 3, 1, 1, 37)])
+def test_output_stationary_conv_is_bit_identical_to_the_pair_list_path(env, ca, co, ks, cur, s, n):
+    """ftx_spconv_ostat (one launch, accumulators in LDS, no pair rows) against ftx_spconv_pairs_gemm + ftx_spconv_reduce on the pair
+    list of the same neighbour table: torch.equal, forward and -- for the symmetric submanifold maps -- the mirrored data gradient;
+    the fused BatchNorm statistics against float64 column sums of the result.  Row counts that are not multiples of 64 / 256."""
+    spf, O = env
+    from fusiontransformer_amd.sparse import CoordinateManager
+    rng = np.random.default_rng(17)
+    c = random_coords(rng, n, extent=30, batch=2)
+    c = c[np.argsort(O.sphash(c))]
+    cm = CoordinateManager()
+    cm.coords[1] = dev(c)
+    st = 1
+    while st < cur:
+        cm.kernel_map(2, st, 2)
+        st *= 2
+    km = cm.kernel_map(ks, cur, s)
+    kvol = ks ** 3
+    assert spf.ostat_supported(ca, co, kvol)
+    x = dev(rng.standard_normal((km.n_in, ca)).astype(np.float32))
+    w = dev((rng.standard_normal((kvol, ca, co)) / np.sqrt(ca * kvol)).astype(np.float32))
+    ref = spf._spconv_apply(x, w, km.pair_in, km.pos, km.koff, km.n_pairs, km.n_out, co, 0)
+    out = spf._spconv_ostat(x, w, km.nbr, km.n_out, co, 0, 0)
+    assert torch.equal(out, ref)
+    L = spf._lib.load()
+    nb = int(L.ftx_spconv_ostat_blocks(km.n_out))
+    part = torch.full(((nb + 1) * 2 * co,), float("nan"), dtype=torch.float64, device="cuda")
+    out2 = spf._spconv_ostat(x, w, km.nbr, km.n_out, co, 0, 0, part=part.data_ptr(), nb=nb)
+    assert torch.equal(out2, ref)
+    tot = part[nb * 2 * co:].view(2, co).cpu()
+    d = ref.double().cpu()
+    np.testing.assert_allclose(tot[0].numpy(), d.sum(0).numpy(), rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(tot[1].numpy(), (d * d).sum(0).numpy(), rtol=1e-11, atol=1e-11)
+    out3 = spf._spconv_ostat(x, w, km.nbr, km.n_out, co, 0, 0, part=part.data_ptr(), nb=nb)     # the tickets were put back to zero
+    assert torch.equal(out3, ref) and torch.equal(part[nb * 2 * co:].view(2, co).cpu(), tot)
+    if s == 1 and spf.ostat_supported(co, ca, kvol, True):
+        assert km.submanifold
+        g = dev(rng.standard_normal((km.n_out, co)).astype(np.float32))
+        ref_g = spf._spconv_apply(g, w, km.pair_out, km.pos_t, km.koff, km.n_pairs, km.n_in, ca, 1)
+        got_g = spf._spconv_ostat(g, w, km.nbr, km.n_in, ca, 1, 1)
+        assert torch.equal(got_g, ref_g)
