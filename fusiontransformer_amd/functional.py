@@ -441,16 +441,33 @@ def _spconv_direct(A, W, gather, scatter, koff, n_pairs, n_rows_out, co, w_trans
 
 
 _OSTAT = os.environ.get("FTX_OSTAT", "1") != "0"      # A/B aid: 0 = every convolution on the pair-list kernels
+_OSTAT_ALL = os.environ.get("FTX_OSTAT", "1") == "all"   # every layer the kernel supports, not only where it is faster
 _OSTAT_OK = {}
 
 
-def ostat_supported(ca, co, kvol, w_transposed=False):
-    """Does the one-launch output-stationary kernel (ftx_spconv_ostat) take this layer?  (ca in {4, 32, 64}, co in {32, 64})"""
+_OSTAT_MAX_ROWS = 64 * 4096      # one block per 64 output rows, at most 4096 partial rows in the statistics hand-over
+
+
+def ostat_supported(ca, co, kvol, w_transposed=False, rows=0):
+    """Does the one-launch output-stationary kernel (ftx_spconv_ostat) take this layer?  (ca in {4, 32, 64}, co in {32, 64},
+    at most 262 144 output rows; anything else runs on the pair-list kernels)"""
     key = (int(ca), int(co), int(kvol), bool(w_transposed))
     v = _OSTAT_OK.get(key)
     if v is None:
         v = _OSTAT_OK[key] = bool(_lib.load().ftx_spconv_ostat_supported(key[0], key[1], key[2], int(key[3])))
-    return v and _OSTAT
+    return v and _OSTAT and rows <= _OSTAT_MAX_ROWS
+
+
+def ostat_preferred(ca, co, kvol, w_transposed=False, rows=0):
+    """Where the output-stationary kernel is FASTER than pair GEMM + reduce on MI355X (tools/bench_spconv.py, profiles/r03_spconv_layer_micro.txt):
+    forward convolutions with c_in <= 32 and c_out = 32 -- the stem, the 32 -> 32 layers of levels 1 and 2, the strided 32 -> 32 layers.
+    It is bound by instruction issue (~23 instructions per pair), so 64-channel layers and the transposed-W data-gradient form lose
+    (csrc/ftx_spconv_ostat.hip); FTX_OSTAT=all routes everything the kernel supports through it (tests, measurements)."""
+    if not ostat_supported(ca, co, kvol, w_transposed, rows):
+        return False
+    if _OSTAT_ALL:
+        return True
+    return (not w_transposed) and co == 32 and ca <= 32
 
 
 def _spconv_ostat(A, W, nbr, n_rows_out, co, w_transposed, flip, part=0, nb=0, pairs=0):
@@ -501,7 +518,7 @@ def _conv_forward(feats, kernel, km, transposed):
     if transposed and km.fine_bijective:
         # every fine row is the destination of exactly one pair: the GEMM epilogue writes `out` itself
         return _spconv_direct(feats, kernel, km.pair_out, km.pair_in, km.koff, km.n_pairs, n_out, co, 0)
-    if not transposed and n_out > 0 and km.n_pairs > 0 and ostat_supported(ca, co, kvol):
+    if not transposed and n_out > 0 and km.n_pairs > 0 and ostat_preferred(ca, co, kvol, rows=n_out):
         return _spconv_ostat(feats, kernel, km.nbr, n_out, co, 0, 0, pairs=km.n_pairs)
     gather, pos = (km.pair_out, km.pos_t) if transposed else (km.pair_in, km.pos)
     return _spconv_apply(feats, kernel, gather, pos, km.koff, km.n_pairs, n_out, co, 0)
@@ -514,7 +531,7 @@ def _conv_backward(feats, kernel, km, transposed, grad_out, need_feats, need_ker
     if need_feats:
         if not transposed and km.fine_bijective:
             g_feats = _spconv_direct(grad_out, kernel, km.pair_out, km.pair_in, km.koff, km.n_pairs, feats.shape[0], ca, 1)
-        elif not transposed and km.submanifold and km.n_pairs > 0 and ostat_supported(co, ca, kvol, True):
+        elif not transposed and km.submanifold and km.n_pairs > 0 and ostat_preferred(co, ca, kvol, True, rows=feats.shape[0]):
             # symmetric map: the data gradient is the same output-stationary kernel on the same table, read mirrored
             g_feats = _spconv_ostat(grad_out, kernel, km.nbr, feats.shape[0], ca, 1, 1, pairs=km.n_pairs)
         else:
@@ -750,7 +767,7 @@ class _ConvBNTrain(torch.autograd.Function):
             _log_launch("bn_fwd", dict(n=n_out, c=co, reads=2 + (residual is not None), writes=1), lambda: check(L.ftx_bn_train_fwd(
                 ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps),
                 n_out, co, int(relu), ptr(y), p_mean, p_invstd, ws, ws_bytes, st), "ftx_bn_train_fwd"))
-        elif not transposed and ostat_supported(ca, co, kvol):
+        elif not transposed and ostat_preferred(ca, co, kvol, rows=n_out):
             # thin layer: convolution + statistics in one launch, then the apply pass
             nb = _ws_bytes("ftx_spconv_ostat_blocks", n_out)
             part, = _carve(feats, 16 * (nb + 1) * co)
@@ -793,7 +810,7 @@ class _ConvBNTrain(torch.autograd.Function):
         bn_ws_bytes = _ws_bytes("ftx_bn_workspace_bytes", n, co)
         in_side, out_side = (km.pair_out, km.pair_in) if transposed else (km.pair_in, km.pair_out)
         direct = need_feats and (not transposed) and km.fine_bijective
-        ostat = need_feats and (not direct) and (not transposed) and km.submanifold and km.n_pairs > 0 and ostat_supported(co, ca, kvol, True)
+        ostat = need_feats and (not direct) and (not transposed) and km.submanifold and km.n_pairs > 0 and ostat_preferred(co, ca, kvol, True, rows=feats.shape[0])
         n_feats = feats.shape[0]
         wg_bytes = _ws_bytes("ftx_spconv_pairs_wgrad_workspace_bytes", km.n_pairs, ca, co, kvol) if (need_kernel and km.n_pairs > 0) else 0
         tmp_bytes = 4 * km.n_pairs * ca if (need_feats and not direct and not ostat) else 0
