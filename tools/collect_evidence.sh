@@ -12,6 +12,10 @@ python tools/bench_attn.py > $O/attn_tilings.txt 2>&1; tail -3 $O/attn_tilings.t
 # N > 1 code path (bucketed overlapped all-reduce, per-rank batches) rehearsed as 2 ranks on this one GPU over gloo: NOT a scaling number
 FTX_DIST_BACKEND=gloo FTX_FORCE_DEVICE=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
   bench.py --gpus 2 --steps 6 --warmup 3 --no-cpu-baseline > $O/bench_2ranks_one_gpu_gloo.json 2> $O/bench_2ranks.err; tail -c 300 $O/bench_2ranks_one_gpu_gloo.json
+# the same path over the REAL backend: a one-rank RCCL communicator, bucketed async all-reduces issued from the autograd hooks inside every step
+python bench.py --steps 20 --warmup 6 --no-cpu-baseline --no-batch1 --no-nuscenes --force-collectives > $O/bench_rccl_one_rank.json 2> $O/bench_rccl_one_rank.err; tail -c 400 $O/bench_rccl_one_rank.json
+# self-launch: plain `python bench.py --gpus 2` with WORLD_SIZE unset becomes the launcher (here 2 ranks share the one GPU over gloo)
+FTX_DIST_BACKEND=gloo FTX_FORCE_DEVICE=0 python bench.py --gpus 2 --steps 3 --warmup 2 --no-cpu-baseline --no-selfcheck > $O/bench_self_launch_2ranks.json 2> $O/bench_self_launch.err; tail -c 300 $O/bench_self_launch_2ranks.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ev_two -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-batch1 --no-nuscenes --no-attention-roofline > $O/prof_two_bench.json 2>/dev/null
 cp $(find /tmp/ev_two -name "*kernel_stats.csv" | head -1) $O/rocprof_two_stream_stats.csv

@@ -6,6 +6,7 @@ def cat(name):
     if 'naive_conv' in name or 'miopenSp3' in name or 'igemm' in name or 'Im2d2Col' in name or 'Col2Im' in name: return 'MIOpen conv'
     if 'pairs_gemm_kernel' in name: return 'ftx spconv pairs_gemm'
     if 'spconv_reduce' in name: return 'ftx spconv reduce'
+    if 'spconv_ostat' in name: return 'ftx spconv ostat (one-launch thin layers)'
     if 'pairs_wgrad_kernel' in name or 'wgrad_reduce' in name: return 'ftx spconv wgrad'
     if 'attn_' in name: return 'ftx attention'
     if name.startswith('Cijk'): return 'hipBLASLt GEMM (Cijk)'
