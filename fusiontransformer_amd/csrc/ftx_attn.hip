@@ -176,6 +176,9 @@ __global__ __launch_bounds__(64 * QW * SPLIT) void attn_fwd_kernel(const float *
   const int hd = blockIdx.y, b = blockIdx.z;
   const int q = blockIdx.x * (32 * QW) + wave * 32 + l31;   // this lane's query (the accumulator column)
   const bool qv = q < T;
+  // 578 tokens = 18 wave-tiles + 2 rows: with 4 waves per block the 20th wave-tile holds no query at all.  Such a wave still stages
+  // tiles and keeps the barriers, but skips its MFMAs and softmax (wave-uniform), leaving the SIMD to the waves beside it.
+  const bool wave_live = blockIdx.x * (32 * QW) + wave * 32 < T;
   const float sl2 = scale * LOG2E;
 
   float qf[32];
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(64 * QW * SPLIT) void attn_fwd_kernel(const float *
       tile_prefetch<NT>(qkv, b, hd, 1, (kt + SPLIT) * 32, T, nh, tid, rk);
       tile_prefetch<NT>(qkv, b, hd, 2, (kt + SPLIT) * 32, T, nh, tid, rv);
     }
-    if (kt < ntiles) {
+    if (kt < ntiles && wave_live) {
       // S^T[key][q] * scale * log2(e): rows = keys of this tile, column = this lane's query
       f32x16 st;
 #pragma unroll
@@ -320,6 +323,7 @@ __global__ __launch_bounds__(64 * QW * SPLIT) void attn_bwd_kv_kernel(const floa
   const int hd = blockIdx.y, b = blockIdx.z;
   const int key = blockIdx.x * (32 * QW) + wave * 32 + l31;   // accumulator column = this lane's key
   const bool kv = key < T;
+  const bool wave_live = blockIdx.x * (32 * QW) + wave * 32 < T;   // a wave-tile with no key at all skips its products (see attn_fwd_kernel)
   const float sl2 = scale * LOG2E;
 
   float kf[32], vf[32];
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(64 * QW * SPLIT) void attn_bwd_kv_kernel(const floa
       tile_prefetch<NT>(qkv, b, hd, 0, (qt + SPLIT) * 32, T, nh, tid, rq);
       tile_prefetch_o<NT>(go, b, hd, (qt + SPLIT) * 32, T, nh, tid, rg);
     }
-    if (qt < ntiles) {
+    if (qt < ntiles && wave_live) {
       // S[q][key] and dP[q][key]: rows = queries of the tile, column = this lane's key
       f32x16 s, dp;
 #pragma unroll
@@ -410,6 +414,7 @@ __global__ __launch_bounds__(64 * QW * SPLIT) void attn_bwd_q_kernel(const float
   const int hd = blockIdx.y, b = blockIdx.z;
   const int q = blockIdx.x * (32 * QW) + wave * 32 + l31;
   const bool qv = q < T;
+  const bool wave_live = blockIdx.x * (32 * QW) + wave * 32 < T;   // a wave-tile with no query at all skips its products (see attn_fwd_kernel)
   const float sl2 = scale * LOG2E;
 
   float qf[32], gf[32];
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(64 * QW * SPLIT) void attn_bwd_q_kernel(const float
       tile_prefetch<NT>(qkv, b, hd, 1, (kt + SPLIT) * 32, T, nh, tid, rk);
       tile_prefetch<NT>(qkv, b, hd, 2, (kt + SPLIT) * 32, T, nh, tid, rv);
     }
-    if (kt < ntiles) {
+    if (kt < ntiles && wave_live) {
       // S^T[key][q], dP^T[key][q]
       f32x16 st, dpt;
 #pragma unroll
