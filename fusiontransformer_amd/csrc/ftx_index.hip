@@ -312,6 +312,146 @@ extern "C" int ftx_gather_coords(const int32_t *src, const int32_t *index, int64
   return check_launch("ftx_gather_coords");
 }
 
+// ---------------------------------------------------------------- all U-Net levels in one pass
+// The voxel sets of every stride the network visits (models/spvcnn.py:104-126: strides 1, 2, 4, 8, 16) are all functions of the POINTS'
+// integer coordinates: level s = unique(floor_div(p, s) * s) in ascending hash order.  The lazy form -- level l+1 from level l, as
+// torchsparse's spdownsample does -- is a chain of five (hash, sort, unique, read the count back) rounds; floor division composes
+// (floor(floor(x/2)/2) = floor(x/4)), so here every level is hashed straight from the points, the L x N (level tag | hash) keys are sorted
+// ONCE, and ONE host read returns all level sizes.  Same sets, same order, same coordinates as the chain (tested bit for bit).
+constexpr int LV_MAX = 8;               // level tags live in bits 60..62 of the key (hashes are 60-bit)
+struct LevelStrides { int32_t s[LV_MAX]; };
+
+__global__ void levels_hash_kernel(const int4 *__restrict__ pts, int64_t n, LevelStrides st, int nl, int64_t *__restrict__ keys, int32_t *__restrict__ vals) {
+  const int64_t total = n * nl;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int l = (int)(e / n);
+    const int64_t i = e - (int64_t)l * n;
+    const int4 c = pts[i];
+    const int s = st.s[l];
+    const int64_t h = fnv_hash4(floor_div(c.x, s) * s, floor_div(c.y, s) * s, floor_div(c.z, s) * s, c.w);
+    keys[e] = ((int64_t)l << 60) | h;
+    vals[e] = (int32_t)i;
+  }
+}
+
+// level_off[l] = first position of level l's run in the sorted unique keys (level_off[nl] = total), by binary search for the tag; every
+// key then loses its tag.  The searches read the tagged keys, so they run in their own launch, before the strip pass.
+__global__ void levels_offsets_kernel(const int64_t *__restrict__ uniq, const int32_t *__restrict__ n_unique, int nl, int32_t *__restrict__ level_off) {
+  const int l = threadIdx.x;
+  if (l > nl) return;
+  const int64_t total = *n_unique;
+  if (l == nl) { level_off[nl] = (int32_t)total; return; }
+  const int64_t want = (int64_t)l << 60;      // first key >= (l << 60)
+  int64_t lo = 0, hi = total;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (uniq[mid] < want) lo = mid + 1; else hi = mid;
+  }
+  level_off[l] = (int32_t)lo;
+}
+__global__ void levels_strip_kernel(int64_t *__restrict__ uniq, const int32_t *__restrict__ n_unique) {
+  const int64_t total = *n_unique;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    uniq[i] &= 0x0FFFFFFFFFFFFFFFLL;
+}
+
+struct LevelsLayout {
+  size_t off_keys, off_keys_sorted, off_vals_in, off_vals_sorted, off_count, off_tmp, tmp_bytes, total;
+};
+static int levels_layout(int64_t n, int nl, LevelsLayout *L) {
+  const size_t m = (size_t)n * nl;
+  size_t sort_bytes = 0, uniq_bytes = 0;
+  int64_t *kp = nullptr;
+  int32_t *vp = nullptr;
+  hipError_t e1 = rocprim::radix_sort_pairs(nullptr, sort_bytes, kp, kp, vp, vp, m, 0u, 63u);
+  hipError_t e2 = rocprim::unique_by_key(nullptr, uniq_bytes, kp, vp, kp, vp, vp, m);
+  if (e1 != hipSuccess || e2 != hipSuccess) {
+    set_error("ftx_levels_unique: rocprim size query failed");
+    return FTX_ELAUNCH;
+  }
+  L->off_keys = 0;
+  L->off_keys_sorted = align256(L->off_keys + sizeof(int64_t) * m);
+  L->off_vals_in = align256(L->off_keys_sorted + sizeof(int64_t) * m);
+  L->off_vals_sorted = align256(L->off_vals_in + sizeof(int32_t) * m);
+  L->off_count = align256(L->off_vals_sorted + sizeof(int32_t) * m);
+  L->off_tmp = align256(L->off_count + 256);
+  L->tmp_bytes = sort_bytes > uniq_bytes ? sort_bytes : uniq_bytes;
+  L->total = align256(L->off_tmp + L->tmp_bytes);
+  return FTX_OK;
+}
+
+extern "C" size_t ftx_levels_workspace_bytes(int64_t n, int32_t n_levels) {
+  if (n <= 0 || n_levels <= 0 || n_levels > LV_MAX) return 256;
+  LevelsLayout L;
+  if (levels_layout(n, n_levels, &L) != FTX_OK) return 0;
+  return L.total;
+}
+
+extern "C" int ftx_levels_unique(const int32_t *points, int64_t n, const int32_t *strides, int32_t n_levels, int64_t *uniq, int32_t *first_index,
+                                 int32_t *level_off, void *workspace, size_t workspace_bytes, void *stream) {
+  FTX_REQUIRE(n >= 0 && n_levels >= 1 && n_levels <= LV_MAX, "ftx_levels_unique: bad size (1..%d levels)", LV_MAX);
+  FTX_REQUIRE(strides && level_off, "ftx_levels_unique: null strides / level_off");
+  LevelStrides ls;
+  for (int l = 0; l < LV_MAX; ++l) ls.s[l] = 1;
+  for (int l = 0; l < n_levels; ++l) {
+    FTX_REQUIRE(strides[l] >= 1, "ftx_levels_unique: strides must be >= 1");
+    ls.s[l] = strides[l];
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) {
+    if (hipMemsetAsync(level_off, 0, sizeof(int32_t) * (n_levels + 1), st) != hipSuccess) return check_launch("ftx_levels_unique memset");
+    return FTX_OK;
+  }
+  FTX_REQUIRE(points && uniq && first_index && workspace, "ftx_levels_unique: null pointer");
+  FTX_REQUIRE(n * n_levels < 0x7fffffff, "ftx_levels_unique: too many keys for int32 rows");
+  LevelsLayout L;
+  int rc = levels_layout(n, n_levels, &L);
+  if (rc != FTX_OK) return rc;
+  if (workspace_bytes < L.total) {
+    set_error("ftx_levels_unique: workspace %zu < required %zu", workspace_bytes, L.total);
+    return FTX_EWORKSPACE;
+  }
+  char *ws = (char *)workspace;
+  int64_t *keys = (int64_t *)(ws + L.off_keys), *keys_sorted = (int64_t *)(ws + L.off_keys_sorted);
+  int32_t *vals_in = (int32_t *)(ws + L.off_vals_in), *vals_sorted = (int32_t *)(ws + L.off_vals_sorted);
+  int32_t *count = (int32_t *)(ws + L.off_count);
+  void *tmp = ws + L.off_tmp;
+  const size_t m = (size_t)n * n_levels;
+  levels_hash_kernel<<<grid_for((int64_t)m, 256), 256, 0, st>>>((const int4 *)points, n, ls, n_levels, keys, vals_in);
+  size_t tb = L.tmp_bytes;
+  // stable radix sort over (tag | hash): equal keys keep ascending point order, so the first of each run is the first occurrence
+  if (rocprim::radix_sort_pairs(tmp, tb, keys, keys_sorted, vals_in, vals_sorted, m, 0u, 63u, st) != hipSuccess) {
+    set_error("ftx_levels_unique: radix sort failed");
+    return FTX_ELAUNCH;
+  }
+  tb = L.tmp_bytes;
+  if (rocprim::unique_by_key(tmp, tb, keys_sorted, vals_sorted, uniq, first_index, count, m, rocprim::equal_to<int64_t>(), st) != hipSuccess) {
+    set_error("ftx_levels_unique: unique_by_key failed");
+    return FTX_ELAUNCH;
+  }
+  levels_offsets_kernel<<<1, 64, 0, st>>>(uniq, count, n_levels, level_off);
+  levels_strip_kernel<<<grid_for((int64_t)m, 256), 256, 0, st>>>(uniq, count);
+  return check_launch("ftx_levels_unique");
+}
+
+// coords of one level: out[r] = floor_div(points[first[r]], stride) * stride (batch column kept): the rows of that level in hash order
+__global__ void level_coords_kernel(const int4 *__restrict__ pts, const int32_t *__restrict__ first, int64_t n, int stride, int4 *__restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int4 v = pts[first[i]];
+    v.x = floor_div(v.x, stride) * stride;
+    v.y = floor_div(v.y, stride) * stride;
+    v.z = floor_div(v.z, stride) * stride;
+    out[i] = v;
+  }
+}
+extern "C" int ftx_level_coords(const int32_t *points, const int32_t *first_index, int64_t n, int32_t stride, int32_t *out, void *stream) {
+  FTX_REQUIRE(n >= 0 && stride >= 1, "ftx_level_coords: bad size / stride");
+  if (n == 0) return FTX_OK;
+  FTX_REQUIRE(points && first_index && out, "ftx_level_coords: null pointer");
+  level_coords_kernel<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>((const int4 *)points, first_index, n, stride, (int4 *)out);
+  return check_launch("ftx_level_coords");
+}
+
 // ---------------------------------------------------------------- kernel maps
 // One thread per (offset k, output row o), o fastest: coordinate reads are 16-byte
 // and re-served from L2 across the K passes, the table probes are the random part.

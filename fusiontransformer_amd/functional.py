@@ -185,6 +185,37 @@ def unique_sorted(keys: torch.Tensor):
     return uniq, first, cnt
 
 
+def levels_unique(points: torch.Tensor, strides):
+    """Every U-Net level's voxel set from the floored point coordinates in ONE pass (ftx_levels_unique): for each stride s the sorted
+    unique hashes of floor_div(p, s) * s and the point row of each one's first occurrence, back to back, plus `level_off`
+    (len(strides) + 1,) int32 ON THE DEVICE -- where each level's run starts.  One sort, no host sync here."""
+    L = _lib.load()
+    req(points, I32, "levels_unique points", 2)
+    if points.shape[1] != 4:
+        raise ValueError("levels_unique: points must be (N,4)")
+    st = np.ascontiguousarray(np.asarray(strides, dtype=np.int32))
+    nl, n = int(st.shape[0]), points.shape[0]
+    if not (1 <= nl <= 8) or (st < 1).any():
+        raise ValueError("levels_unique: 1..8 strides, each >= 1")
+    uniq = _empty((nl * n,), I64, points)
+    first = _empty((nl * n,), I32, points)
+    level_off = _empty((nl + 1,), I32, points)
+    ws_bytes = _ws_bytes("ftx_levels_workspace_bytes", n, nl)
+    ws = _scratch(ws_bytes, points)
+    check(L.ftx_levels_unique(ptr(points), n, st.ctypes.data, nl, ptr(uniq), ptr(first), ptr(level_off), ptr(ws), ws_bytes, stream()), "ftx_levels_unique")
+    return uniq, first, level_off
+
+
+def level_coords(points: torch.Tensor, first_index: torch.Tensor, stride: int) -> torch.Tensor:
+    """Coordinates of one level: floor_div(points[first_index], stride) * stride, rows in the level's (hash) order."""
+    L = _lib.load()
+    req(points, I32, "level_coords points", 2)
+    req(first_index, I32, "level_coords first_index", 1)
+    out = _empty((first_index.shape[0], 4), I32, points)
+    check(L.ftx_level_coords(ptr(points), ptr(first_index), first_index.shape[0], int(stride), ptr(out), stream()), "ftx_level_coords")
+    return out
+
+
 def sorted_rank(sorted_keys: torch.Tensor, n_sorted: torch.Tensor, queries: torch.Tensor) -> torch.Tensor:
     """Position of every query in sorted_keys[:n_sorted] (ascending, unique), -1 when absent; n_sorted is a (1,) int32 DEVICE tensor,
     so `unique_sorted` + `sorted_rank` give numpy.unique(return_index, return_inverse) without a host read."""

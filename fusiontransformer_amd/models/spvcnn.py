@@ -305,7 +305,8 @@ class SPVCNN(nn.Module):
         if os.environ.get("FTX_EAGER_INDEX_READS") == "1":   # A/B aid: block on every read as it comes
             x0 = initial_voxelize(z, self.pres, self.vres)
         else:
-            x0 = yield from initial_voxelize_steps(z, self.pres, self.vres)
+            levels = None if os.environ.get("FTX_LAZY_LEVELS") == "1" else (1, 2, 4, 8, 16)   # A/B aid: 1 = level l+1 from level l, six reads
+            x0 = yield from initial_voxelize_steps(z, self.pres, self.vres, levels=levels)
             yield from x0.cm.unet_levels_steps((1, 2, 4, 8, 16))
         if ahead:
             cm, seg = x0.cm, torch.is_grad_enabled()

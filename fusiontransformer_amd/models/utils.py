@@ -18,24 +18,43 @@ def initial_voxelize(z: PointTensor, init_res, after_res) -> SparseTensor:
     return drain(initial_voxelize_steps(z, init_res, after_res))
 
 
-def initial_voxelize_steps(z: PointTensor, init_res, after_res):
-    """initial_voxelize as a generator that yields "sync" before the voxel count is read back (sparse.HostRead)."""
+def initial_voxelize_steps(z: PointTensor, init_res, after_res, levels=None):
+    """initial_voxelize as a generator that yields "sync" before the voxel count is read back (sparse.HostRead).
+
+    `levels`: the strides the network will visit, starting with 1 (SPVCNN: (1, 2, 4, 8, 16)).  Every level's voxel set is then taken
+    from the points in ONE pass (functional.levels_unique) and the single host read returns all level sizes; the CoordinateManager
+    keeps the per-level hashes / first occurrences and builds each level's coordinates and hash table from them without another read
+    (the lazy form -- level l+1 from level l, one read per level -- remains for `levels=None`).  Same sets, order and coordinates."""
     if init_res == after_res:
         new_float_coord = z.C
     else:
         new_float_coord = torch.cat([(z.C[:, :3] * init_res) / after_res, z.C[:, -1].view(-1, 1)], 1).contiguous()
     floored = spf.floor_coords(new_float_coord, 1)           # torch.floor(...).int()
     pc_hash = spf.sphash(floored)
-    uniq, first, cnt = spf.unique_sorted(pc_hash)            # torch.unique(pc_hash)
-    pending = HostRead(cnt)
-    yield "sync"
-    n_vox = pending.value()
-    sparse_hash = uniq[:n_vox].contiguous()
+    level_data = None
+    if levels is not None:
+        levels = tuple(int(s) for s in levels)
+        if not levels or levels[0] != 1:
+            raise ValueError("initial_voxelize: `levels` must start with stride 1")
+        uniq_all, first_all, level_off = spf.levels_unique(floored, levels)
+        pending = HostRead(level_off)
+        yield "sync"
+        offs = pending.values()
+        level_data = {s: (uniq_all[offs[i]:offs[i + 1]], first_all[offs[i]:offs[i + 1]]) for i, s in enumerate(levels)}
+        sparse_hash, first1 = level_data[1]
+        n_vox = sparse_hash.shape[0]
+    else:
+        uniq, first, cnt = spf.unique_sorted(pc_hash)        # torch.unique(pc_hash)
+        pending = HostRead(cnt)
+        yield "sync"
+        n_vox = pending.value()
+        sparse_hash = uniq[:n_vox].contiguous()
+        first1 = first[:n_vox].contiguous()
     table = spf.HashTable(sparse_hash)
     idx_query = table.query(pc_hash)                         # spf.sphashquery(pc_hash, sparse_hash)
     counts = spf.spcount(idx_query, n_vox)
     # round(mean of identical integer coordinates) == the coordinates of any member
-    inserted_coords = spf.gather_coords(floored, first[:n_vox].contiguous())
+    inserted_coords = spf.gather_coords(floored, first1)
     seg = spf.voxelize_segments(idx_query, n_vox)
     inserted_feat = spf.spvoxelize(z.F, idx_query, counts, seg)
 
@@ -43,6 +62,8 @@ def initial_voxelize_steps(z: PointTensor, init_res, after_res):
     new_tensor.cm = CoordinateManager()
     new_tensor.cm.coords[1] = inserted_coords
     new_tensor.cm.tables[1] = table                          # keys == sphash(inserted_coords), row order == table rows
+    if level_data is not None:
+        new_tensor.cm.points, new_tensor.cm.level_data = floored, level_data
     new_tensor.check()
     z.additional_features["idx_query"][1] = idx_query
     z.additional_features["counts"][1] = counts

@@ -44,6 +44,10 @@ class CoordinateManager:
         self.coords = {}       # stride -> (N,4) int32
         self.kernel_maps = {}  # (ks, cur_stride, stride) -> KernelMap
         self._offsets = {}
+        # set by initial_voxelize(levels=...): the floored point coordinates and, per stride, (sorted unique hashes, first-occurrence
+        # point rows) of that level -- every level's coordinates and hash table then come without a host read (_materialize_level)
+        self.points = None
+        self.level_data = None
 
     def offsets(self, ks, stride, device):
         key = (ks, stride)
@@ -55,6 +59,16 @@ class CoordinateManager:
         if stride not in self.tables:
             self.tables[stride] = Fn.HashTable(Fn.sphash(self.coords[stride]))
         return self.tables[stride]
+
+    def _materialize_level(self, stride):
+        """Coordinates and hash table of a level that initial_voxelize(levels=...) already found: no sort, no host read."""
+        if stride in self.coords or not self.level_data or stride not in self.level_data:
+            return stride in self.coords
+        hashes, first = self.level_data[stride]
+        self.coords[stride] = Fn.level_coords(self.points, first, stride)
+        if stride not in self.tables:
+            self.tables[stride] = Fn.HashTable(hashes)      # == sphash(coords[stride]): the level's rows are in hash order
+        return True
 
     def kernel_map(self, ks, cur_stride, stride) -> KernelMap:
         key = (ks, cur_stride, stride)
@@ -79,7 +93,7 @@ class CoordinateManager:
             out_coords = coords
         else:
             new_stride = cur_stride * stride
-            if new_stride not in self.coords:
+            if new_stride not in self.coords and not self._materialize_level(new_stride):
                 yield from self.downsample_steps(cur_stride, stride)
             out_coords = self.coords[new_stride]
         nbr = Fn.kernel_map_build(out_coords, off, table)
@@ -119,9 +133,27 @@ class CoordinateManager:
 
     def unet_levels_steps(self, strides, ks=3, down_ks=2):
         """Everything a U-Net over `strides` will ask for -- the kernel-`ks` submanifold map of every level and
-        the strided kernel-`down_ks` map between consecutive levels -- built up front.  The two data-dependent
-        sizes of a level (its pair count and the voxel count of the next level) come back in ONE host read
-        per level, after a "sync" yield."""
+        the strided kernel-`down_ks` map between consecutive levels -- built up front.
+
+        When the levels were found by initial_voxelize(levels=...) every level's coordinates are already known, so the neighbour
+        tables of ALL levels are built first and their data-dependent pair counts come back in ONE host read (after a single "sync"
+        yield).  Otherwise (lazy form) the two data-dependent sizes of a level -- its pair count and the voxel count of the next level
+        -- come back in one read per level."""
+        if self.level_data and all(s in self.level_data for s in strides):
+            pend = []
+            for s in strides:
+                self._materialize_level(s)
+                coords = self.coords[s]
+                nbr = Fn.kernel_map_build(coords, self.offsets(ks, s, coords.device), self.table(s))
+                pos, koff = Fn.kernel_map_count(nbr)
+                pend.append((s, coords, nbr, pos, koff))
+            pending = HostRead(torch.cat([koff[-1:] for _, _, _, _, koff in pend]))
+            yield "sync"
+            for (s, coords, nbr, pos, koff), n_pairs in zip(pend, pending.values()):
+                self._finish_map((ks, s, 1), nbr, pos, koff, n_pairs, coords.shape[0], coords)
+            for s, nxt in zip(strides[:-1], strides[1:]):
+                drain(self.kernel_map_steps(down_ks, s, nxt // s))   # no host read: P = N_in, the next level exists
+            return
         for i, s in enumerate(strides):
             coords = self.coords[s]
             n_in = coords.shape[0]

@@ -92,6 +92,17 @@ int ftx_downsample_coords(const int32_t *coords, int64_t n, int32_t ratio, int32
 /* out[i,:] = src[index[i],:] for int32 rows of width 4 (coordinate gather). */
 int ftx_gather_coords(const int32_t *src, const int32_t *index, int64_t n, int32_t *out, void *stream);
 
+/* Every level of the U-Net in ONE pass (models/spvcnn.py:104-126 visits strides 1, 2, 4, 8, 16; torchsparse's spdownsample derives
+ * level l+1 from level l, one hash + torch.unique + size read per level): points (n,4) int32 = the floored point coordinates;
+ * for each of the n_levels strides (HOST array, each >= 1, at most 8) the set unique(floor_div(p, s) * s) in ascending hash order.
+ * uniq (n_levels*n) int64: the levels' sorted unique hashes back to back; first_index (n_levels*n): the point row of the first
+ * occurrence of each; level_off (n_levels+1) int32 DEVICE: where each level's run starts (level_off[n_levels] = total).  The caller
+ * reads level_off once (the only host read of the whole coordinate build besides the pair counts) and takes the level's coordinates
+ * with ftx_level_coords(points, first_index + level_off[l], n_l, stride, out).  Same sets, order and coordinates as the chained form. */
+size_t ftx_levels_workspace_bytes(int64_t n, int32_t n_levels);
+int ftx_levels_unique(const int32_t *points, int64_t n, const int32_t *strides, int32_t n_levels, int64_t *uniq, int32_t *first_index, int32_t *level_off, void *workspace, size_t workspace_bytes, void *stream);
+int ftx_level_coords(const int32_t *points, const int32_t *first_index, int64_t n, int32_t stride, int32_t *out, void *stream);
+
 /* ---- kernel maps (inside spnn.Conv3d): models/spvcnn.py:26-30,42-46,57-72,99-101 */
 
 /* nbr[k, o] = row in the table's key set of (out_coords[o] + offsets[k]), or -1.

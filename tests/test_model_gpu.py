@@ -438,3 +438,53 @@ def test_eager_training_pass_switches_later_captures_off():
     (l2 + l3).backward()
     torch.cuda.synchronize()
     assert not trunk.__dict__.get("_graph_cache"), "captured although captures were switched off"
+
+
+def test_one_pass_level_build_equals_the_chained_build():
+    """initial_voxelize(levels=(1, 2, 4, 8, 16)) takes every level's voxel set from the points in one sort and ONE host read
+    (functional.levels_unique), and unet_levels_steps then needs ONE more read for all pair counts: 2 reads per batch instead of 6.
+    Coordinates, hash tables' keys, neighbour tables, pair lists and offsets of every level must equal the chained build bit for bit;
+    points with duplicates and negative coordinates included (floor division composes: floor(floor(x / 2) / 2) = floor(x / 4))."""
+    from fusiontransformer_amd import functional as spf
+    from fusiontransformer_amd.data.synth import make_batch
+    from fusiontransformer_amd.models.utils import initial_voxelize, initial_voxelize_steps
+    from fusiontransformer_amd.sparse import PointTensor
+    b = make_batch([0, 1], max_points=5000)
+    rng = np.random.default_rng(3)
+    coords = torch.from_numpy(b["coords"]).float()
+    coords[:, :3] -= 37.0                                                  # negative coordinates
+    coords = torch.cat([coords, coords[rng.integers(0, coords.shape[0], 400)]]).cuda()   # duplicate points: several points per voxel
+    feats = torch.randn(coords.shape[0], 4, device="cuda")
+    strides = (1, 2, 4, 8, 16)
+
+    gen = initial_voxelize_steps(PointTensor(feats, coords.clone()), 1, 1, levels=strides)
+    tokens = []
+    while True:
+        try:
+            tokens.append(next(gen))
+        except StopIteration as done:
+            x_a = done.value
+            break
+    gen = x_a.cm.unet_levels_steps(strides)
+    try:
+        while True:
+            tokens.append(next(gen))
+    except StopIteration:
+        pass
+    assert tokens == ["sync", "sync"], tokens
+
+    x_b = initial_voxelize(PointTensor(feats, coords.clone()), 1, 1)     # chained form
+    from fusiontransformer_amd.sparse import drain
+    drain(x_b.cm.unet_levels_steps(strides))
+    assert torch.equal(x_a.F, x_b.F) and torch.equal(x_a.C, x_b.C)
+    for s in strides:
+        assert torch.equal(x_a.cm.coords[s], x_b.cm.coords[s]), s
+        ta, tb = x_a.cm.table(s), x_b.cm.table(s)
+        q = spf.sphash(x_b.cm.coords[s])
+        assert torch.equal(ta.query(q), tb.query(q)) and torch.equal(ta.query(q), torch.arange(q.shape[0], device="cuda", dtype=torch.int32)), s
+    assert x_a.cm.kernel_maps.keys() == x_b.cm.kernel_maps.keys() and len(x_a.cm.kernel_maps) == 9
+    for key, ka in x_a.cm.kernel_maps.items():
+        kb = x_b.cm.kernel_maps[key]
+        assert (ka.n_pairs, ka.n_in, ka.n_out) == (kb.n_pairs, kb.n_in, kb.n_out), key
+        for f in ("nbr", "pos", "pos_t", "pair_in", "pair_out", "koff", "out_coords"):
+            assert torch.equal(getattr(ka, f), getattr(kb, f)), (key, f)
