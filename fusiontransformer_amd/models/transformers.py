@@ -305,35 +305,56 @@ class Image2DTransformer(nn.Module):
                     if on_block is not None:
                         on_block(last, outputs[str(last)])
             return outputs
+        infer = self._inference_graph(x)
+        if infer is not None:
+            # validate()'s forward (data/utils/validate.py:59): the whole live trunk as ONE forward-only HIP graph; the tapped outputs
+            # are copies, so a later replay does not change tensors the caller still holds
+            outputs = dict()
+            for i, t in infer(x):
+                outputs[str(i)] = t[:, self.num_tokens:, :] if self.remove_tokens_outputs else t
+                if on_block is not None:
+                    on_block(i, outputs[str(i)])
+            return outputs
         if x.is_cuda and self.training and torch.is_grad_enabled():
             # This pass and its backward run eagerly.  A capture attempted AFTER an eager backward through these parameters
             # aborts the process inside hipStreamEndCapture on torch 2.10 / ROCm 7 (tools/probes/graph_recapture.py) -- an abort,
             # not an exception -- so from here on no NEW capture is attempted (already captured shapes keep replaying).
             self._capture_off("an eager training pass ran through the trunk before the capture")
-        x = self._embed(x)
         outputs = dict()
+
+        def emit(i, t):
+            outputs[str(i)] = t[:, self.num_tokens:, :] if self.remove_tokens_outputs else t
+            if on_block is not None:
+                on_block(i, outputs[str(i)])
+
+        self._forward_eager(x, emit)
+        return outputs
+
+    def _forward_eager(self, x, emit, want=None):
+        """The live blocks, eagerly; emit(i, tokens) for every block i (want=None: what the reference's forward_blocks returns) or only
+        for the blocks in `want`.
+
+        Same residual-stream form as the captured segments (_TrunkSegment): inside a segment the stream stays (r, p, pb) from block to
+        block, at a segment end it becomes one tensor -- so the eager trunk and the graphed trunk run the SAME kernels in the same order
+        and agree to the last bit in every gradient.  A block's output in between is materialised for the caller only."""
+        x = self._embed(x)
         live = [b for i, b in enumerate(self.blocks) if self.last_block is None or i <= self.last_block]
-        # Same residual-stream form as the captured segments (_TrunkSegment): inside a segment the stream stays (r, p, pb) from block to
-        # block, at a segment end it becomes one tensor -- so the eager trunk and the graphed trunk run the SAME kernels in the same order
-        # and agree to the last bit in every gradient.  A block's output in between is materialised for the caller only.
         ends = set(self._segment_ends()) if self.graph_taps else None      # no taps known: every block ends a segment
         chained = x.is_cuda and ends is not None and all(b._fused(x) for b in live)
         r, p, pb = x, None, None
         for i, block in enumerate(live):
+            need = want is None or i in want
             if chained:
                 r, p, pb = block.chain(r, p, pb)
-                x = _materialize(r, p, pb)
                 if i in ends:
+                    x = _materialize(r, p, pb)
                     r, p, pb = x, None, None
+                elif need:
+                    x = _materialize(r, p, pb)
             else:
                 x = block(x)
-            if self.remove_tokens_outputs:
-                outputs[str(i)] = x[:, self.num_tokens:, :]
-            else:
-                outputs[str(i)] = x
-            if on_block is not None:
-                on_block(i, outputs[str(i)])
-        return outputs
+            if need:
+                emit(i, x)
 
     # ---- HIP-graph execution of the trunk ------------------------------------------------------------------
     graph_taps = None   # sorted block indices whose outputs the caller uses; None: eager execution
@@ -371,6 +392,56 @@ class Image2DTransformer(nn.Module):
                 cache[key] = None
                 self._capture_off("capture refused: %s: %s" % (type(err).__name__, err))
         return cache[key]
+
+    # ---- forward-only graph for evaluation -----------------------------------------------------------------------------------
+    eval_graphs = os.environ.get("FTX_VIT_EVAL_GRAPHS", "1") != "0"
+
+    def _inference_graph(self, x):
+        """Replay function of the forward-only HIP graph for this input shape, or None (not on the GPU, gradients enabled, training
+        mode, taps unknown, or the capture was refused).  No autograd node is created under no_grad, so the restriction of the
+        training capture (never after an eager backward, see forward_blocks) does not apply."""
+        if (not self.eval_graphs or not self.graph_taps or not self.use_graphs or not x.is_cuda or self.training or torch.is_grad_enabled()
+                or torch.cuda.is_current_stream_capturing()):
+            return None
+        cache = self.__dict__.setdefault("_infer_cache", {})
+        flags = tuple((blk.attn.attn_impl, bool(getattr(blk.attn.qkv, "ftx_bf16", False))) for blk in self.blocks)
+        key = (tuple(x.shape), x.dtype, tuple(self.graph_taps), self.last_block, flags, torch.cuda.current_device())
+        if key not in cache:
+            try:
+                cache[key] = self._capture_inference(x)
+            except Exception as err:     # refused: run eagerly from now on for this shape
+                import sys
+                print("[fusiontransformer_amd] forward-only HIP-graph capture of the ViT trunk failed (%s: %s); evaluation runs it eagerly" % (type(err).__name__, err),
+                      file=sys.stderr, flush=True)
+                cache[key] = None
+        return cache[key]
+
+    def _capture_inference(self, x):
+        taps = sorted(int(t) for t in self.graph_taps)
+        static_in = x.detach().clone()
+
+        def run(inp):
+            got = {}
+            self._forward_eager(inp, lambda i, t: got.__setitem__(i, t), want=set(taps))
+            return [got[t] for t in taps]
+
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):
+                run(static_in)                                  # warm-up: lazy initialisation, TunableOp selections, scratch growth
+        cur.wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(graph):
+            static_out = run(static_in)
+
+        def replay(inp):
+            static_in.copy_(inp)
+            graph.replay()
+            return [(t, o.clone()) for t, o in zip(taps, static_out)]
+
+        return replay
 
     def _capture_off(self, reason):
         if not self.__dict__.get("_graph_capture_off", False):

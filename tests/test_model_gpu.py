@@ -488,3 +488,39 @@ def test_one_pass_level_build_equals_the_chained_build():
         assert (ka.n_pairs, ka.n_in, ka.n_out) == (kb.n_pairs, kb.n_in, kb.n_out), key
         for f in ("nbr", "pos", "pos_t", "pair_in", "pair_out", "koff", "out_coords"):
             assert torch.equal(getattr(ka, f), getattr(kb, f)), (key, f)
+
+
+def test_evaluation_runs_the_trunk_as_one_forward_only_graph():
+    """validate()'s forward (reference data/utils/validate.py:59): in eval mode under no_grad the ViT trunk replays as ONE forward-only HIP
+    graph per input shape.  Logits bit-identical to the eager trunk; replays on other images of the same shape are right (the graph reads a
+    static input copy); it may be captured AFTER training steps (no autograd node is involved), and training goes on afterwards."""
+    from fusiontransformer_amd.data.synth import make_batch
+    from fusiontransformer_amd.trainer import TrainStep
+    cfg, oracle, model, _ = _pair("middle", seed=7)
+    trunk = model.image_backbone.backbone
+    step = TrainStep(cfg, model)
+    pins = [product_inputs(make_batch([s, s + 1], max_points=2500)) for s in (0, 2, 4)]
+    model.train()
+    for pin in pins[:2]:
+        step(pin)                                   # graphed training steps come first
+    model.eval()
+    outs = []
+    with torch.no_grad():
+        for pin in pins:
+            outs.append({k: v.clone() for k, v in model(pin).items()})
+    assert trunk.__dict__.get("_infer_cache") and all(v is not None for v in trunk._infer_cache.values()), "no forward-only graph was captured"
+    trunk.eval_graphs = False
+    with torch.no_grad():
+        for pin, got in zip(pins, outs):
+            ref = model(pin)
+            for k in ref:
+                assert torch.equal(ref[k], got[k]), k
+    trunk.eval_graphs = True
+    oracle.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})      # the trained state, running statistics included
+    with torch.no_grad():                           # the oracle agrees as well
+        ref = oracle.eval()(oracle_inputs(make_batch([4, 5], max_points=2500)))
+    for k in ref:
+        assert (outs[2][k].cpu() - ref[k]).abs().max().item() <= TOL, k
+    model.train()
+    step(pins[0])                                   # and training continues on its captured graphs
+    assert trunk.graph_state() == "on"
