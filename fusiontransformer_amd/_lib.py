@@ -37,7 +37,8 @@ SIGNATURES = {
     "ftx_downsample_coords": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "ftx_gather_coords": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "ftx_levels_workspace_bytes": (_sz, [_i64, _i32]),
-    "ftx_levels_unique": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ftx_levels_unique": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ftx_level_segments": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp]),
     "ftx_level_coords": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "ftx_kernel_map_build": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp, _i64, _vp, _vp]),
     "ftx_kernel_map_count_workspace_bytes": (_sz, [_i64, _i32]),

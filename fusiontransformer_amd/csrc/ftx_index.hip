@@ -388,7 +388,7 @@ extern "C" size_t ftx_levels_workspace_bytes(int64_t n, int32_t n_levels) {
 }
 
 extern "C" int ftx_levels_unique(const int32_t *points, int64_t n, const int32_t *strides, int32_t n_levels, int64_t *uniq, int32_t *first_index,
-                                 int32_t *level_off, void *workspace, size_t workspace_bytes, void *stream) {
+                                 int32_t *level_off, int64_t *sorted_keys, int32_t *order, void *workspace, size_t workspace_bytes, void *stream) {
   FTX_REQUIRE(n >= 0 && n_levels >= 1 && n_levels <= LV_MAX, "ftx_levels_unique: bad size (1..%d levels)", LV_MAX);
   FTX_REQUIRE(strides && level_off, "ftx_levels_unique: null strides / level_off");
   LevelStrides ls;
@@ -412,8 +412,10 @@ extern "C" int ftx_levels_unique(const int32_t *points, int64_t n, const int32_t
     return FTX_EWORKSPACE;
   }
   char *ws = (char *)workspace;
-  int64_t *keys = (int64_t *)(ws + L.off_keys), *keys_sorted = (int64_t *)(ws + L.off_keys_sorted);
-  int32_t *vals_in = (int32_t *)(ws + L.off_vals_in), *vals_sorted = (int32_t *)(ws + L.off_vals_sorted);
+  // sorted_keys / order (optional outputs): the n_levels x n (tag | hash) keys in sorted order and the point of each -- level l owns
+  // [l*n, (l+1)*n): its points sorted by voxel, stable, i.e. the sorted segments of spvoxelize at that stride (ftx_level_segments)
+  int64_t *keys = (int64_t *)(ws + L.off_keys), *keys_sorted = sorted_keys ? sorted_keys : (int64_t *)(ws + L.off_keys_sorted);
+  int32_t *vals_in = (int32_t *)(ws + L.off_vals_in), *vals_sorted = order ? order : (int32_t *)(ws + L.off_vals_sorted);
   int32_t *count = (int32_t *)(ws + L.off_count);
   void *tmp = ws + L.off_tmp;
   const size_t m = (size_t)n * n_levels;
@@ -432,6 +434,29 @@ extern "C" int ftx_levels_unique(const int32_t *points, int64_t n, const int32_t
   levels_offsets_kernel<<<1, 64, 0, st>>>(uniq, count, n_levels, level_off);
   levels_strip_kernel<<<grid_for((int64_t)m, 256), 256, 0, st>>>(uniq, count);
   return check_launch("ftx_levels_unique");
+}
+
+// seg_off[v] = first position, among the n sorted keys of ONE level (tag | hash, ascending), of voxel v's run: a lower bound per voxel.
+// With `order` = that level's slice of ftx_levels_unique's sorted points this is exactly what ftx_segment_build(idx_query, n, m) returns
+// for the point -> voxel index of the level, without sorting anything again.
+__global__ void level_segments_kernel(const int64_t *__restrict__ sorted_keys, int64_t n, const int64_t *__restrict__ uniq, int64_t m, int64_t tag,
+                                      int32_t *__restrict__ seg_off) {
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v <= m; v += (int64_t)gridDim.x * blockDim.x) {
+    if (v == m) { seg_off[m] = (int32_t)n; continue; }
+    const int64_t want = (tag << 60) | uniq[v];
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (sorted_keys[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    seg_off[v] = (int32_t)lo;
+  }
+}
+extern "C" int ftx_level_segments(const int64_t *sorted_keys, int64_t n, const int64_t *uniq, int64_t m, int32_t level, int32_t *seg_off, void *stream) {
+  FTX_REQUIRE(n >= 0 && m >= 0 && level >= 0 && level < LV_MAX, "ftx_level_segments: bad size / level");
+  FTX_REQUIRE(seg_off && (m == 0 || (sorted_keys && uniq)), "ftx_level_segments: null pointer");
+  level_segments_kernel<<<grid_for(m + 1, 256), 256, 0, (hipStream_t)stream>>>(sorted_keys, n, uniq, m, (int64_t)level, seg_off);
+  return check_launch("ftx_level_segments");
 }
 
 // coords of one level: out[r] = floor_div(points[first[r]], stride) * stride (batch column kept): the rows of that level in hash order

@@ -200,10 +200,25 @@ def levels_unique(points: torch.Tensor, strides):
     uniq = _empty((nl * n,), I64, points)
     first = _empty((nl * n,), I32, points)
     level_off = _empty((nl + 1,), I32, points)
+    sorted_keys = _empty((nl, n), I64, points)        # row l: level l's (tag | hash) keys, ascending
+    order = _empty((nl, n), I32, points)              # row l: the points sorted by their voxel of level l (stable)
     ws_bytes = _ws_bytes("ftx_levels_workspace_bytes", n, nl)
     ws = _scratch(ws_bytes, points)
-    check(L.ftx_levels_unique(ptr(points), n, st.ctypes.data, nl, ptr(uniq), ptr(first), ptr(level_off), ptr(ws), ws_bytes, stream()), "ftx_levels_unique")
-    return uniq, first, level_off
+    check(L.ftx_levels_unique(ptr(points), n, st.ctypes.data, nl, ptr(uniq), ptr(first), ptr(level_off), ptr(sorted_keys), ptr(order), ptr(ws), ws_bytes,
+                              stream()), "ftx_levels_unique")
+    return uniq, first, level_off, sorted_keys, order
+
+
+def level_segments(sorted_keys_row: torch.Tensor, order_row: torch.Tensor, hashes: torch.Tensor, level: int) -> "Segments":
+    """The sorted segments of spvoxelize at one level from levels_unique's sort (no second sort): == Segments(idx_query, n_vox)."""
+    L = _lib.load()
+    req(sorted_keys_row, I64, "level_segments sorted keys", 1)
+    req(order_row, I32, "level_segments order", 1)
+    req(hashes, I64, "level_segments hashes", 1)
+    m = hashes.shape[0]
+    seg_off = _empty((m + 1,), I32, hashes)
+    check(L.ftx_level_segments(ptr(sorted_keys_row), sorted_keys_row.shape[0], ptr(hashes), m, int(level), ptr(seg_off), stream()), "ftx_level_segments")
+    return Segments.from_parts(order_row, seg_off, m)
 
 
 def level_coords(points: torch.Tensor, first_index: torch.Tensor, stride: int) -> torch.Tensor:
@@ -311,6 +326,12 @@ def calc_ti_weights(pc: torch.Tensor, idx_query: torch.Tensor, scale: int = 1) -
 class Segments:
     """Entries sorted by destination row (ftx_segment_build): `order`, `seg_off`, `m` rows."""
     __slots__ = ("order", "seg_off", "m")
+
+    @classmethod
+    def from_parts(cls, order, seg_off, m):
+        self = cls.__new__(cls)
+        self.order, self.seg_off, self.m = order, seg_off, int(m)
+        return self
 
     def __init__(self, keys: torch.Tensor, m: int):
         L = _lib.load()

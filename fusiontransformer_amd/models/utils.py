@@ -36,12 +36,13 @@ def initial_voxelize_steps(z: PointTensor, init_res, after_res, levels=None):
         levels = tuple(int(s) for s in levels)
         if not levels or levels[0] != 1:
             raise ValueError("initial_voxelize: `levels` must start with stride 1")
-        uniq_all, first_all, level_off = spf.levels_unique(floored, levels)
+        uniq_all, first_all, level_off, sorted_keys, order = spf.levels_unique(floored, levels)
         pending = HostRead(level_off)
         yield "sync"
         offs = pending.values()
-        level_data = {s: (uniq_all[offs[i]:offs[i + 1]], first_all[offs[i]:offs[i + 1]]) for i, s in enumerate(levels)}
-        sparse_hash, first1 = level_data[1]
+        # per level: (sorted unique hashes, first-occurrence point rows, level index, the level's sorted keys, its points sorted by voxel)
+        level_data = {s: (uniq_all[offs[i]:offs[i + 1]], first_all[offs[i]:offs[i + 1]], i, sorted_keys[i], order[i]) for i, s in enumerate(levels)}
+        sparse_hash, first1 = level_data[1][:2]
         n_vox = sparse_hash.shape[0]
     else:
         uniq, first, cnt = spf.unique_sorted(pc_hash)        # torch.unique(pc_hash)
@@ -55,7 +56,7 @@ def initial_voxelize_steps(z: PointTensor, init_res, after_res, levels=None):
     counts = spf.spcount(idx_query, n_vox)
     # round(mean of identical integer coordinates) == the coordinates of any member
     inserted_coords = spf.gather_coords(floored, first1)
-    seg = spf.voxelize_segments(idx_query, n_vox)
+    seg = _level_segments(level_data, 1) if level_data is not None else spf.voxelize_segments(idx_query, n_vox)
     inserted_feat = spf.spvoxelize(z.F, idx_query, counts, seg)
 
     new_tensor = SparseTensor(inserted_feat, inserted_coords, 1)
@@ -72,13 +73,20 @@ def initial_voxelize_steps(z: PointTensor, init_res, after_res, levels=None):
     return new_tensor
 
 
+def _level_segments(level_data, stride):
+    """Points sorted by their voxel at `stride`, from the one-pass level sort (no second sort)."""
+    hashes, _, level, skeys, order = level_data[stride]
+    return spf.level_segments(skeys, order, hashes, level)
+
+
 def voxel_index(cm: CoordinateManager, stride: int, z: PointTensor, n_vox: int):
     """The coordinate-only half of point_to_voxel at `stride` (hash query, counts, sorted segments), cached on `z`."""
     pc_hash = spf.sphash(spf.floor_coords(z.C, stride))
     idx_query = cm.table(stride).query(pc_hash)              # sphashquery(pc_hash, sphash(x.C))
     z.additional_features["idx_query"][stride] = idx_query
     z.additional_features["counts"][stride] = spf.spcount(idx_query, n_vox)
-    z.additional_features.setdefault("vox_seg", {})[stride] = spf.voxelize_segments(idx_query, n_vox)
+    ld = getattr(cm, "level_data", None)
+    z.additional_features.setdefault("vox_seg", {})[stride] = _level_segments(ld, stride) if (ld and stride in ld) else spf.voxelize_segments(idx_query, n_vox)
 
 
 def point_index(cm: CoordinateManager, stride: int, z: PointTensor, n_vox: int, nearest=False, with_segments=True):

@@ -64,7 +64,7 @@ class CoordinateManager:
         """Coordinates and hash table of a level that initial_voxelize(levels=...) already found: no sort, no host read."""
         if stride in self.coords or not self.level_data or stride not in self.level_data:
             return stride in self.coords
-        hashes, first = self.level_data[stride]
+        hashes, first = self.level_data[stride][:2]
         self.coords[stride] = Fn.level_coords(self.points, first, stride)
         if stride not in self.tables:
             self.tables[stride] = Fn.HashTable(hashes)      # == sphash(coords[stride]): the level's rows are in hash order

@@ -100,7 +100,12 @@ int ftx_gather_coords(const int32_t *src, const int32_t *index, int64_t n, int32
  * reads level_off once (the only host read of the whole coordinate build besides the pair counts) and takes the level's coordinates
  * with ftx_level_coords(points, first_index + level_off[l], n_l, stride, out).  Same sets, order and coordinates as the chained form. */
 size_t ftx_levels_workspace_bytes(int64_t n, int32_t n_levels);
-int ftx_levels_unique(const int32_t *points, int64_t n, const int32_t *strides, int32_t n_levels, int64_t *uniq, int32_t *first_index, int32_t *level_off, void *workspace, size_t workspace_bytes, void *stream);
+int ftx_levels_unique(const int32_t *points, int64_t n, const int32_t *strides, int32_t n_levels, int64_t *uniq, int32_t *first_index, int32_t *level_off, int64_t *sorted_keys, int32_t *order, void *workspace, size_t workspace_bytes, void *stream);
+/* sorted_keys / order (n_levels*n each, may be NULL): the (level tag << 60 | hash) keys in sorted order and the point row of each; level l
+ * owns [l*n, (l+1)*n): its points sorted by voxel, stable.  ftx_level_segments turns that slice into the sorted segments of spvoxelize at
+ * the level's stride (what ftx_segment_build(idx_query, n, m) would return) without another sort: seg_off (m+1) from the level's unique
+ * hashes (`uniq + level_off[l]`, m = n_l of them). */
+int ftx_level_segments(const int64_t *sorted_keys, int64_t n, const int64_t *uniq, int64_t m, int32_t level, int32_t *seg_off, void *stream);
 int ftx_level_coords(const int32_t *points, const int32_t *first_index, int64_t n, int32_t stride, int32_t *out, void *stream);
 
 /* ---- kernel maps (inside spnn.Conv3d): models/spvcnn.py:26-30,42-46,57-72,99-101 */

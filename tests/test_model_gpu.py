@@ -524,3 +524,29 @@ def test_evaluation_runs_the_trunk_as_one_forward_only_graph():
     model.train()
     step(pins[0])                                   # and training continues on its captured graphs
     assert trunk.graph_state() == "on"
+
+
+def test_level_segments_from_the_one_pass_sort_equal_the_sorted_segments():
+    """functional.level_segments (seg_off by binary search in the one-pass level sort, order = that sort's point order) against
+    Segments(idx_query, n_vox) -- the rocPRIM sort it replaces -- for every stride the network voxelises at, duplicates included."""
+    from fusiontransformer_amd import functional as spf
+    from fusiontransformer_amd.data.synth import make_batch
+    from fusiontransformer_amd.models.utils import _level_segments, initial_voxelize_steps, voxel_index
+    from fusiontransformer_amd.sparse import PointTensor, drain
+    b = make_batch([3], max_points=4000)
+    rng = np.random.default_rng(5)
+    coords = torch.from_numpy(b["coords"]).float()
+    coords = torch.cat([coords, coords[rng.integers(0, coords.shape[0], 700)]]).cuda()
+    z = PointTensor(torch.randn(coords.shape[0], 4, device="cuda"), coords)
+    x0 = drain(initial_voxelize_steps(z, 1, 1, levels=(1, 2, 4, 8, 16)))
+    drain(x0.cm.unet_levels_steps((1, 2, 4, 8, 16)))
+    for s in (1, 4, 16):
+        n_vox = x0.cm.coords[s].shape[0]
+        if s > 1:
+            voxel_index(x0.cm, s, z, n_vox)
+        idx = z.additional_features["idx_query"][s]
+        ref = spf.Segments(idx, n_vox)
+        got = _level_segments(x0.cm.level_data, s)
+        assert got.m == ref.m and torch.equal(got.seg_off, ref.seg_off), s
+        assert torch.equal(got.order, ref.order), s
+        assert z.additional_features["vox_seg"][s].order.data_ptr() == x0.cm.level_data[s][4].data_ptr()     # the model uses the free ones
