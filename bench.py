@@ -111,7 +111,7 @@ def spconv_roofline(log, workload=None):
             "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "launches": bn["launches"], "ms": round(bn["ms"], 3), "algorithmic_bytes_per_step": int(bn["bytes"]),
             "bytes_rule": "4*N*C per row matrix read or written: forward x (+residual) in, y out -- x twice when the statistics are not produced by the "
-                          "convolution's reduce pass; backward two passes over (gy, x, y-mask), gx (+ residual gradient) out"}
+                          "convolution's reduce pass; backward two passes over (gy, x) -- plus y for the ReLU mask only where a residual went into it, otherwise the mask is recomputed from x --, gx (+ residual gradient) out"}
     if attn["ms"] > 0:
         tf = attn["flops"] / (attn["ms"] * 1e-3) / 1e12
         other["attention (attn_fwd / attn_bwd_kv / attn_bwd_q)"] = {

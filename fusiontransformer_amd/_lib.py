@@ -97,7 +97,7 @@ SIGNATURES = {
     "ftx_fusion_loss_mix": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ftx_project_points": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp]),
     "ftx_eval_scatter_back": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "ftx_bn_train_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ftx_bn_train_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

@@ -123,14 +123,23 @@ extern "C" size_t ftx_bn_workspace_bytes(int64_t n, int32_t c) {
 // Per-block partial column sums of two quantities (q0, q1) produced by `Op` for each element.
 //   forward:  q0 = x,        q1 = x*x
 //   backward: q0 = dy,       q1 = dy * xhat      (dy masked by y>0 when relu)
+// y = (x - mean) * invstd * gamma + beta with the rounding of every step pinned (no contraction left to the compiler): the forward apply
+// pass and the ReLU mask the backward RECOMPUTES from x (instead of reading y back: a third of the backward's traffic for the
+// BatchNorm + ReLU layers that have no residual) must agree to the last bit.
+__device__ inline float bn_affine(float x, float mean, float invstd, float gamma, float beta) {
+  return __fmaf_rn(__fmul_rn(__fsub_rn(x, mean), invstd), gamma, beta);
+}
+
 struct FwdOp {
-  __device__ static void eval(float x, float, float, float, float, int, double &q0, double &q1) {
+  __device__ static void eval(float x, float, float, float, float, float, float, int, double &q0, double &q1) {
     q0 = (double)x;
     q1 = (double)x * (double)x;
   }
 };
+// relu: 0 none, 1 mask from the stored forward output y, 2 mask recomputed from x (no residual went into y)
 struct BwdOp {
-  __device__ static void eval(float x, float gy, float y, float mean, float invstd, int relu, double &q0, double &q1) {
+  __device__ static void eval(float x, float gy, float y, float mean, float invstd, float gamma, float beta, int relu, double &q0, double &q1) {
+    if (relu == 2) y = bn_affine(x, mean, invstd, gamma, beta);
     float dy = (relu && !(y > 0.f)) ? 0.f : gy;
     q0 = (double)dy;
     q1 = (double)dy * (double)((x - mean) * invstd);
@@ -140,7 +149,8 @@ struct BwdOp {
 template <class Op>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                          const float *__restrict__ y, const float *__restrict__ mean,
-                                                         const float *__restrict__ invstd, int relu, int64_t n, int c,
+                                                         const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta, int relu, int64_t n, int c,
                                                          double *part, StreamScratch sc) {
   // part: gridDim.x rows [2][c], then the totals row [2][c] written by the last block to finish (ftx_lastblock.h)
   extern __shared__ double sh[];  // [2][RL][c]
@@ -153,17 +163,21 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict
   const int64_t r1 = (r0 + rows_per_block < n) ? r0 + rows_per_block : n;
   double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
   if (rl < RL) {
-    float4 mu = make_float4(0, 0, 0, 0), is = mu;
+    float4 mu = make_float4(0, 0, 0, 0), is = mu, gm = mu, bt = mu;
     if (mean) {
       mu = *(const float4 *)&mean[cg * 4];
       is = *(const float4 *)&invstd[cg * 4];
     }
+    if (relu == 2) {
+      gm = *(const float4 *)&gamma[cg * 4];
+      bt = *(const float4 *)&beta[cg * 4];
+    }
     auto accumulate = [&](const float4 &xv, const float4 &gv, const float4 &yv) {
       double a, b;
-      Op::eval(xv.x, gv.x, yv.x, mu.x, is.x, relu, a, b); s0[0] += a; s1[0] += b;
-      Op::eval(xv.y, gv.y, yv.y, mu.y, is.y, relu, a, b); s0[1] += a; s1[1] += b;
-      Op::eval(xv.z, gv.z, yv.z, mu.z, is.z, relu, a, b); s0[2] += a; s1[2] += b;
-      Op::eval(xv.w, gv.w, yv.w, mu.w, is.w, relu, a, b); s0[3] += a; s1[3] += b;
+      Op::eval(xv.x, gv.x, yv.x, mu.x, is.x, gm.x, bt.x, relu, a, b); s0[0] += a; s1[0] += b;
+      Op::eval(xv.y, gv.y, yv.y, mu.y, is.y, gm.y, bt.y, relu, a, b); s0[1] += a; s1[1] += b;
+      Op::eval(xv.z, gv.z, yv.z, mu.z, is.z, gm.z, bt.z, relu, a, b); s0[2] += a; s1[2] += b;
+      Op::eval(xv.w, gv.w, yv.w, mu.w, is.w, gm.w, bt.w, relu, a, b); s0[3] += a; s1[3] += b;
     };
     const float4 zero4 = make_float4(0, 0, 0, 0);
     int64_t r = r0 + rl;
@@ -240,10 +254,10 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float *__restri
     const int64_t o = r * c + col;
     const float4 xv = *(const float4 *)&x[o];
     float4 ov;
-    ov.x = (xv.x - mu.x) * is.x * g.x + b.x;
-    ov.y = (xv.y - mu.y) * is.y * g.y + b.y;
-    ov.z = (xv.z - mu.z) * is.z * g.z + b.z;
-    ov.w = (xv.w - mu.w) * is.w * g.w + b.w;
+    ov.x = bn_affine(xv.x, mu.x, is.x, g.x, b.x);
+    ov.y = bn_affine(xv.y, mu.y, is.y, g.y, b.y);
+    ov.z = bn_affine(xv.z, mu.z, is.z, g.z, b.z);
+    ov.w = bn_affine(xv.w, mu.w, is.w, g.w, b.w);
     if (res) {
       const float4 rv = *(const float4 *)&res[o];
       ov.x += rv.x; ov.y += rv.y; ov.z += rv.z; ov.w += rv.w;
@@ -300,7 +314,7 @@ extern "C" int ftx_bn_train_fwd(const float *x, const float *residual, const flo
   if (!sc.counters) return FTX_ELAUNCH;
   const int nb = bn_blocks(n);
   double *part = (double *)workspace;
-  bn_partial_kernel<FwdOp><<<nb, 256, bn_partial_lds(c), st>>>(x, nullptr, nullptr, nullptr, nullptr, 0, n, c, part, sc);
+  bn_partial_kernel<FwdOp><<<nb, 256, bn_partial_lds(c), st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n, c, part, sc);
   bn_apply_fwd_kernel<<<bn_apply_grid(n, c), 256, 0, st>>>(x, residual, gamma, beta, part + (size_t)nb * 2 * c, eps, momentum, running_mean,
                                                            running_var, save_mean, save_invstd, n, c, relu, y);
   return check_launch("ftx_bn_train_fwd");
@@ -356,7 +370,8 @@ extern "C" int ftx_bn_eval_fwd(const float *x, const float *residual, const floa
 }
 
 __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restrict__ gy, const float *__restrict__ x, const float *__restrict__ y,
-                                                           const float *__restrict__ gamma, const float *__restrict__ mean,
+                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                           const float *__restrict__ mean,
                                                            const float *__restrict__ invstd, const double *__restrict__ sums, int64_t n, int c,
                                                            int relu, float *__restrict__ gx, float *__restrict__ gres,
                                                            float *__restrict__ grad_gamma, float *__restrict__ grad_beta) {
@@ -366,12 +381,13 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restri
   if (rl >= RL) return;
   const int col = cg * 4;
   const float inv_n = 1.f / (float)n;
-  float mu[4], is[4], gm[4], sdy[4], sdyx[4];
+  float mu[4], is[4], gm[4], bt[4], sdy[4], sdyx[4];
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     mu[v] = mean[col + v];
     is[v] = invstd[col + v];
     gm[v] = gamma[col + v];
+    bt[v] = relu == 2 ? beta[col + v] : 0.f;
     sdy[v] = (float)sums[col + v] * inv_n;
     sdyx[v] = (float)sums[c + col + v] * inv_n;
     if (blockIdx.x == 0 && rl == 0) {   // the parameter gradients are the two totals themselves
@@ -385,7 +401,11 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restri
     const float4 x4 = *(const float4 *)&x[o];
     float dy[4] = {g4.x, g4.y, g4.z, g4.w};
     const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
-    if (relu) {
+    if (relu == 2) {          // the forward output recomputed from x (bit for bit: bn_affine), not read back
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (!(bn_affine(xv[v], mu[v], is[v], gm[v], bt[v]) > 0.f)) dy[v] = 0.f;
+    } else if (relu) {
       const float4 y4 = *(const float4 *)&y[o];
       const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
 #pragma unroll
@@ -410,14 +430,17 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restri
   if (r < n) one(r);
 }
 
-extern "C" int ftx_bn_train_bwd(const float *grad_y, const float *x, const float *y, const float *gamma, const float *save_mean,
+extern "C" int ftx_bn_train_bwd(const float *grad_y, const float *x, const float *y, const float *gamma, const float *beta, const float *save_mean,
                                 const float *save_invstd, int64_t n, int32_t c, int32_t relu, float *grad_x, float *grad_residual,
                                 float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream) {
   int rc = bn_check("ftx_bn_train_bwd", n, c);
   if (rc != FTX_OK) return rc;
   FTX_REQUIRE(n >= 1, "ftx_bn_train_bwd: needs at least one row");
   FTX_REQUIRE(grad_y && x && gamma && save_mean && save_invstd && grad_x && workspace, "ftx_bn_train_bwd: null pointer");
-  FTX_REQUIRE(!relu || y, "ftx_bn_train_bwd: relu needs the forward output y");
+  // ReLU mask: recomputed from x when the forward had no residual and beta is given (y is then not read and may be NULL), else from y
+  const bool remask = relu && beta != nullptr && grad_residual == nullptr;
+  FTX_REQUIRE(!relu || remask || y, "ftx_bn_train_bwd: relu needs the forward output y (or beta, when no residual went into it)");
+  const int rmode = !relu ? 0 : (remask ? 2 : 1);
   FTX_REQUIRE(c <= 512, "ftx_bn_train_bwd: c > 512 unsupported");
   if (workspace_bytes < ftx_bn_workspace_bytes(n, c)) {
     set_error("ftx_bn_train_bwd: workspace %zu < required %zu", workspace_bytes, ftx_bn_workspace_bytes(n, c));
@@ -429,8 +452,8 @@ extern "C" int ftx_bn_train_bwd(const float *grad_y, const float *x, const float
   const int nb = bn_blocks(n);
   double *part = (double *)workspace;
   double *sums = part + (size_t)nb * 2 * c;   // written by the last block of the statistics pass
-  bn_partial_kernel<BwdOp><<<nb, 256, bn_partial_lds(c), st>>>(x, grad_y, relu ? y : nullptr, save_mean, save_invstd, relu, n, c, part, sc);
-  bn_apply_bwd_kernel<<<bn_apply_grid(n, c), 256, 0, st>>>(grad_y, x, y, gamma, save_mean, save_invstd, sums, n, c, relu, grad_x, grad_residual,
+  bn_partial_kernel<BwdOp><<<nb, 256, bn_partial_lds(c), st>>>(x, grad_y, rmode == 1 ? y : nullptr, save_mean, save_invstd, gamma, beta, rmode, n, c, part, sc);
+  bn_apply_bwd_kernel<<<bn_apply_grid(n, c), 256, 0, st>>>(grad_y, x, y, gamma, beta, save_mean, save_invstd, sums, n, c, rmode, grad_x, grad_residual,
                                                            grad_gamma, grad_beta);
   return check_launch("ftx_bn_train_bwd");
 }

@@ -730,16 +730,16 @@ class _BatchNormTrain(torch.autograd.Function):
         _log_launch("bn_fwd", dict(n=n, c=c, reads=2 + (residual is not None), writes=1), lambda: check(L.ftx_bn_train_fwd(
             ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps),
             n, c, int(relu), ptr(y), ptr(mean), ptr(invstd), ptr(ws), ws_bytes, _stream_scratch()), "ftx_bn_train_fwd"))
-        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        ctx.save_for_backward(x, y, gamma, beta, mean, invstd)
         ctx.relu = int(relu)
         ctx.has_res = residual is not None
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, y, gamma, mean, invstd = ctx.saved_tensors
+        x, y, gamma, beta, mean, invstd = ctx.saved_tensors
         gy = req(gy.contiguous(), F32, "bn grad", 2)
-        gx, gres, ggamma, gbeta = _bn_backward_launch(gy, x, y, gamma, mean, invstd, ctx.relu, ctx.has_res)
+        gx, gres, ggamma, gbeta = _bn_backward_launch(gy, x, y, gamma, beta, mean, invstd, ctx.relu, ctx.has_res)
         return gx, gres, ggamma, gbeta, None, None, None, None, None
 
 
@@ -768,7 +768,13 @@ class _BatchNormEval(torch.autograd.Function):
         return gx, (dy if ctx.has_res else None), None, None, None, None, None, None
 
 
-def _bn_backward_launch(gy, x, y, gamma, mean, invstd, relu, has_res):
+def _remask_beta(beta):
+    """beta for ftx_bn_train_bwd: with it the ReLU mask of a residual-free BatchNorm is recomputed from x instead of read from y
+    (FTX_BN_REMASK=0 withholds it: A/B aid, read at call time)."""
+    return 0 if os.environ.get("FTX_BN_REMASK") == "0" else ptr(beta)
+
+
+def _bn_backward_launch(gy, x, y, gamma, beta, mean, invstd, relu, has_res):
     L = _lib.load()
     n, c = x.shape
     gx = torch.empty_like(x)
@@ -777,9 +783,10 @@ def _bn_backward_launch(gy, x, y, gamma, mean, invstd, relu, has_res):
     gbeta = _empty((c,), F32, x)
     ws_bytes = _ws_bytes("ftx_bn_workspace_bytes", n, c)
     ws = _scratch(ws_bytes, x)
-    # two passes (statistics, apply), each reading gy and x (and y for the ReLU mask); one or two row matrices written
-    _log_launch("bn_bwd", dict(n=n, c=c, reads=2 * (2 + (1 if relu else 0)), writes=1 + (1 if has_res else 0)), lambda: check(L.ftx_bn_train_bwd(
-        ptr(gy), ptr(x), ptr(y), ptr(gamma), ptr(mean), ptr(invstd), n, c, int(relu), ptr(gx), ptr(gres), ptr(ggamma),
+    # two passes (statistics, apply), each reading gy and x (and y for the ReLU mask when a residual went into it: otherwise the mask is
+    # recomputed from x); one or two row matrices written
+    _log_launch("bn_bwd", dict(n=n, c=c, reads=2 * (2 + (1 if (relu and has_res) else 0)), writes=1 + (1 if has_res else 0)), lambda: check(L.ftx_bn_train_bwd(
+        ptr(gy), ptr(x), ptr(y), ptr(gamma), _remask_beta(beta), ptr(mean), ptr(invstd), n, c, int(relu), ptr(gx), ptr(gres), ptr(ggamma),
         ptr(gbeta), ptr(ws), ws_bytes, _stream_scratch()), "ftx_bn_train_bwd"))
     return gx, gres, ggamma, gbeta
 
@@ -842,14 +849,14 @@ class _ConvBNTrain(torch.autograd.Function):
             _log_launch("bn_fwd", dict(n=n_out, c=co, reads=1 + (residual is not None), writes=1), lambda: check(L.ftx_bn_train_fwd_totals(
                 ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum),
                 float(eps), n_out, co, int(relu), ptr(y), p_mean, p_invstd, part + 16 * nb * co, st), "ftx_bn_train_fwd_totals"))
-        ctx.save_for_backward(feats, kernel, x, y, gamma, stats)
+        ctx.save_for_backward(feats, kernel, x, y, gamma, beta, stats)
         ctx.km, ctx.transposed, ctx.relu, ctx.has_res = km, transposed, int(relu), residual is not None
         return y
 
     @staticmethod
     def backward(ctx, gy):
         L = _lib.load()
-        feats, kernel, x, y, gamma, stats = ctx.saved_tensors
+        feats, kernel, x, y, gamma, beta, stats = ctx.saved_tensors
         km, transposed = ctx.km, ctx.transposed
         gy = req(gy.contiguous(), F32, "conv_bn grad", 2)
         n, co = x.shape
@@ -868,8 +875,8 @@ class _ConvBNTrain(torch.autograd.Function):
         tmp_bytes = 4 * km.n_pairs * ca if (need_feats and not direct and not ostat) else 0
         bn_ws, gx, tmp, wg_ws = _carve(x, bn_ws_bytes, 4 * n * co, tmp_bytes, wg_bytes)
         # BatchNorm half: gx = d loss / d (convolution output) stays in the scratch buffer, it is consumed by the two calls below
-        _log_launch("bn_bwd", dict(n=n, c=co, reads=2 * (2 + (1 if ctx.relu else 0)), writes=1 + (1 if ctx.has_res else 0)), lambda: check(L.ftx_bn_train_bwd(
-            ptr(gy), ptr(x), ptr(y), ptr(gamma), p_mean, p_invstd, n, co, ctx.relu, gx, ptr(gres), gparams.data_ptr(), gparams.data_ptr() + 4 * co,
+        _log_launch("bn_bwd", dict(n=n, c=co, reads=2 * (2 + (1 if (ctx.relu and ctx.has_res) else 0)), writes=1 + (1 if ctx.has_res else 0)), lambda: check(L.ftx_bn_train_bwd(
+            ptr(gy), ptr(x), ptr(y), ptr(gamma), _remask_beta(beta), p_mean, p_invstd, n, co, ctx.relu, gx, ptr(gres), gparams.data_ptr(), gparams.data_ptr() + 4 * co,
             bn_ws, bn_ws_bytes, st), "ftx_bn_train_bwd"))
         g_feats = g_kernel = None
         meta = dict(pairs=km.n_pairs, n_out=n_feats, ca=co, co=ca, kvol=kvol)

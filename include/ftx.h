@@ -260,9 +260,11 @@ int ftx_bn_train_fwd_totals(const float *x, const float *residual, const float *
 
 /* Eval forward with running statistics. */
 int ftx_bn_eval_fwd(const float *x, const float *residual, const float *gamma, const float *beta, const float *running_mean, const float *running_var, float eps, int64_t n, int32_t c, int32_t relu, float *y, void *stream);
-/* Training backward.  y is the forward output (needed for the ReLU mask when relu!=0).
+/* Training backward.  ReLU mask (relu != 0): when the forward had NO residual (grad_residual == NULL) and `beta` is given, the forward
+ * output is RECOMPUTED from x -- bit for bit the value the forward wrote -- and y is not read (it may be NULL): a third of this pass's
+ * traffic; otherwise y, the forward output, supplies the mask.
  * grad_x (n,c), grad_residual (n,c, may be NULL), grad_gamma (c), grad_beta (c). */
-int ftx_bn_train_bwd(const float *grad_y, const float *x, const float *y, const float *gamma, const float *save_mean, const float *save_invstd, int64_t n, int32_t c, int32_t relu, float *grad_x, float *grad_residual, float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream);
+int ftx_bn_train_bwd(const float *grad_y, const float *x, const float *y, const float *gamma, const float *beta, const float *save_mean, const float *save_invstd, int64_t n, int32_t c, int32_t relu, float *grad_x, float *grad_residual, float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- optimizer step: torch.optim.Adam (L2 weight decay, no amsgrad) over every parameter tensor in one launch ----
  * (common/solver/build.py:7-20 builds the optimizer, modules/SemanticTrainer.py:141-209 steps it once per batch.)

@@ -37,11 +37,11 @@ for n, c, count, relu, res in SHAPES:
                                      mean.data_ptr(), inv.data_ptr(), ws.data_ptr(), ws_bytes, st)
     gy = torch.randn(n, c, device="cuda"); gx = torch.empty_like(x); gres = torch.empty_like(x) if res else None
     gg, gb = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
-    bwd = lambda: L.ftx_bn_train_bwd(gy.data_ptr(), x.data_ptr(), y.data_ptr(), g.data_ptr(), mean.data_ptr(), inv.data_ptr(), n, c, relu, gx.data_ptr(), spf.ptr(gres),
+    bwd = lambda: L.ftx_bn_train_bwd(gy.data_ptr(), x.data_ptr(), y.data_ptr(), g.data_ptr(), b.data_ptr(), mean.data_ptr(), inv.data_ptr(), n, c, relu, gx.data_ptr(), spf.ptr(gres),
                                      gg.data_ptr(), gb.data_ptr(), ws.data_ptr(), ws_bytes, st)
     t_f, t_b = timeit(fwd), timeit(bwd)
     by_f = 4.0 * n * c * (2 + (1 if res else 0) + 1)             # x twice (+ residual), y out
-    by_b = 4.0 * n * c * (2 * (2 + relu) + 1 + (1 if res else 0))  # two passes over gy, x (, y), gx (+ gres) out
+    by_b = 4.0 * n * c * (2 * (2 + (1 if (relu and res) else 0)) + 1 + (1 if res else 0))  # two passes over gy, x (, y when a residual went into it), gx (+ gres) out
     print("%8d %5d %3d | %8.1f %8.0f | %8.1f %8.0f" % (n, c, count, t_f, by_f / t_f / 1e3, t_b, by_b / t_b / 1e3))
     tf += count * t_f; tb += count * t_b; bf += count * by_f; bb += count * by_b
 print("per step (weighted by count): fwd %.0f us at %.0f GB/s, bwd %.0f us at %.0f GB/s" % (tf, bf / tf / 1e3, tb, bb / tb / 1e3))
