@@ -8,6 +8,8 @@ cd $R && timeout -k 10 900 python -m pytest tests -q -m gpu 2>&1 | tail -3 > $O/
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
 python bench.py > $O/bench.json 2> $O/bench.err && tail -c 600 $O/bench.json
 python tools/bench_spconv.py > $O/spconv_layer_micro.txt 2>&1; tail -1 $O/spconv_layer_micro.txt
+python tools/bench_bn.py > $O/bn_layer_micro.txt 2>&1; tail -1 $O/bn_layer_micro.txt
+python tools/probes/eval_throughput.py > $O/eval_throughput.txt 2>&1; tail -2 $O/eval_throughput.txt
 python tools/bench_attn.py > $O/attn_tilings.txt 2>&1; tail -3 $O/attn_tilings.txt
 # N > 1 code path (bucketed overlapped all-reduce, per-rank batches) rehearsed as 2 ranks on this one GPU over gloo: NOT a scaling number
 FTX_DIST_BACKEND=gloo FTX_FORCE_DEVICE=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
