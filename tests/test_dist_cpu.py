@@ -114,3 +114,44 @@ def test_forced_collectives_at_world_size_one():
     assert p.exitcode == 0
     assert ok, "a one-rank all-reduce changed the gradients"
     assert nb > 1 and rebuilt and calls >= 3 * nb, (calls, nb)
+
+
+def _reorder_worker(port, q):
+    """From step 1 only the last-ready parameter of each bucket keeps a hook.  If the gradient-ready ORDER changes in a later step -- the
+    tail fires while another gradient of its bucket is still missing -- the bucket must not go out early: it waits for finish()."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    from fusiontransformer_amd.dist import GradReducer, init_process_group
+    init_process_group("gloo", force=True)
+    torch.manual_seed(4)
+    a, b = torch.nn.Linear(6, 6), torch.nn.Linear(6, 6)
+    model = torch.nn.ModuleList([a, b])
+    red = GradReducer(model, bucket_mb=1e-9, force_collectives=True)      # one parameter per bucket
+    x = torch.randn(3, 6)
+
+    def step(order):
+        red.begin_step()
+        outs = {"a": a(x).pow(2).sum(), "b": b(x).pow(2).sum()}
+        for name in order:                       # two separate backward calls fix the order in which the gradients arrive
+            outs[name].backward()
+        red.finish()
+        return [p.grad.clone() for p in model.parameters()]
+
+    g0 = step("ab")
+    g1 = step("ab")                              # buckets rebuilt in the recorded order, one hook per bucket
+    early = red.hook_stats["early_launches"]
+    g2 = step("ba")                              # the order flips: nothing may go out before its bucket is complete
+    ok = all(torch.equal(u, v) for u, v in zip(g0, g1)) and all(torch.equal(u, v) for u, v in zip(g0, g2))
+    q.put((ok, red._rebuilt, len(red.buckets), early, red.hook_stats["deferred"]))
+    dist.destroy_process_group()
+
+
+def test_bucket_waits_when_the_gradient_order_changes():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_reorder_worker, args=(_free_port(), q))
+    p.start()
+    ok, rebuilt, nb, early, deferred = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert ok, "gradients changed when the ready order changed"
+    assert rebuilt and nb == 4 and early >= 1 and deferred >= 1, (nb, early, deferred)

@@ -841,3 +841,48 @@ def test_output_stationary_conv_is_bit_identical_to_the_pair_list_path(env, ca, 
         ref_g = spf._spconv_apply(g, w, km.pair_out, km.pos_t, km.koff, km.n_pairs, km.n_in, ca, 1)
         got_g = spf._spconv_ostat(g, w, km.nbr, km.n_in, ca, 1, 1)
         assert torch.equal(got_g, ref_g)
+
+
+def test_levels_unique_edge_cases(env):
+    """ftx_levels_unique / ftx_level_coords / ftx_level_segments: one level == unique_sorted; eight levels; a single point; no point;
+    every level against numpy.unique of the floor-divided coordinates (negative coordinates included)."""
+    spf, O = env
+    rng = np.random.default_rng(23)
+    pts = np.concatenate([rng.integers(-40, 40, size=(3000, 3)), rng.integers(0, 3, size=(3000, 1))], 1).astype(np.int32)
+    pts = np.concatenate([pts, pts[:500]])                       # duplicates
+    dp = dev(pts)
+    # one level: the same as unique_sorted on the plain hashes
+    uniq, first, off, skeys, order = spf.levels_unique(dp, (1,))
+    u2, f2, cnt = spf.unique_sorted(spf.sphash(dp))
+    n1 = int(cnt.item())
+    assert off.cpu().tolist() == [0, n1]
+    assert torch.equal(uniq[:n1], u2[:n1]) and torch.equal(first[:n1], f2[:n1])
+    # eight levels, against numpy
+    strides = (1, 2, 3, 4, 8, 16, 32, 64)
+    uniq, first, off, skeys, order = spf.levels_unique(dp, strides)
+    offs = off.cpu().tolist()
+    assert len(offs) == 9 and offs[0] == 0
+    for i, s in enumerate(strides):
+        c = pts.copy()
+        c[:, :3] = np.floor_divide(c[:, :3], s) * s
+        h = O.sphash(c)
+        ref_h, ref_first = np.unique(h, return_index=True)
+        n_l = offs[i + 1] - offs[i]
+        assert n_l == len(ref_h), s
+        assert np.array_equal(uniq[offs[i]:offs[i + 1]].cpu().numpy(), ref_h), s
+        assert np.array_equal(first[offs[i]:offs[i + 1]].cpu().numpy(), ref_first), s
+        coords = spf.level_coords(dp, first[offs[i]:offs[i + 1]], s).cpu().numpy()
+        assert np.array_equal(coords, c[ref_first]), s
+        seg = spf.level_segments(skeys[i], order[i], uniq[offs[i]:offs[i + 1]], i)
+        inv = np.searchsorted(ref_h, h).astype(np.int32)        # point -> voxel index of this level
+        ref_seg = spf.Segments(dev(inv), n_l)
+        assert torch.equal(seg.seg_off, ref_seg.seg_off) and torch.equal(seg.order, ref_seg.order), s
+    # a single point, and none
+    one = dev(pts[:1])
+    uniq, first, off, _, _ = spf.levels_unique(one, (1, 2))
+    assert off.cpu().tolist() == [0, 1, 2] and first[:2].cpu().tolist() == [0, 0]
+    none = dev(pts[:0])
+    uniq, first, off, _, _ = spf.levels_unique(none, (1, 2, 4))
+    assert off.cpu().tolist() == [0, 0, 0, 0]
+    with pytest.raises(ValueError):
+        spf.levels_unique(dp, tuple(range(1, 10)))               # more than 8 levels
