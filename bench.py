@@ -300,9 +300,9 @@ def main():
                          "each kernel's duration is then its own, as in the roofline block's HIP-event timings)")
     ap.add_argument("--no-attention-roofline", action="store_true",
                     help="skip the standalone timing of the attention kernels after the timed region (profiling runs: keeps their launch counts per step exact)")
-    ap.add_argument("--index-prefetch", action="store_true",
-                    help="build the coordinate structures of batch i+1 during step i (TrainStep(next_batch=...)) instead of inside its own forward; "
-                         "measured slower on MI355X (batch 4: 128.8 against 139.7 frames/s), off by default")
+    ap.add_argument("--no-index-prefetch", dest="index_prefetch", action="store_false",
+                    help="build the coordinate structures of every batch inside its own forward instead of starting the build of batch i+1 "
+                         "during step i (TrainStep(batch, next_batch): non-blocking start + bounded polling, trainer.py)")
     ap.add_argument("--no-tune-gemm", dest="tune_gemm", action="store_false", help="skip TunableOp selection of the library GEMM kernels")
     ap.add_argument("--force-collectives", action="store_true",
                     help="N = 1 only: create a one-rank RCCL communicator and run the gradient exchange of the N > 1 path (bucketed async all-reduces "
@@ -371,7 +371,7 @@ def main():
 
     if rank == 0:
         log("model and %d resident batches (%s points) resident; warm-up" % (len(datas), points))
-    # --index-prefetch: while step i runs, the coordinate structures of batch i+1 are built on a third stream (TrainStep(next_batch=...)).
+    # index prefetch (default): while step i runs, the index build of batch i+1 is started on a third stream (TrainStep(batch, next_batch)).
     # Every step then builds exactly one set -- the one the NEXT step consumes -- so the K timed steps contain K index builds either way.
     nxt = (lambda seq, i: seq[(i + 1) % len(seq)]) if args.index_prefetch else (lambda seq, i: None)
     for i in range(args.warmup):
@@ -434,7 +434,7 @@ def main():
                        "frames_per_gpu": args.batch, "global_batch": args.batch * world, "points_per_gpu_batch": n_points,
                        "resident_batches_cycled": len(datas), "points_of_each_resident_batch": points,
                        "attention": args.attn, "library_gemm_tuning": bool(args.tune_gemm), "branch_overlap": "off (--serial-branches)" if args.serial_branches else "2 HIP streams (image / LiDAR)",
-                       "index_prefetch": ("coordinate structures of batch i+1 built during step i on a third stream; one build per timed step" if args.index_prefetch
+                       "index_prefetch": ("index build of batch i+1 started during step i on a third stream without blocking the host, finished by its forward; one build per timed step" if args.index_prefetch
                                           else "off: every batch's coordinate structures are built inside its own forward"),
                        "parallelism": "dp%d" % world},
             "frames_per_sec_per_gpu": round(frames / elapsed / world, 3),

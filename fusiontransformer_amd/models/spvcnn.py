@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import functional as spf
-from ..sparse import PointTensor, PreparedIndex, SparseTensor, cat, drain, index_stream as _index_stream
+from ..sparse import PendingIndex, PointTensor, PreparedIndex, SparseTensor, cat, drain, index_stream as _index_stream
 from .utils import initial_voxelize, initial_voxelize_steps, point_index, point_to_voxel, voxel_index, voxel_to_point
 
 __all__ = ["SPVCNN", "Conv3d", "BatchNorm", "ReLU"]
@@ -234,6 +234,12 @@ class SPVCNN(nn.Module):
         the issue of this branch with the image branch (see _fusion_common.run_fusion).  It yields
         "need_early" / "need_middle" right before it touches the image features."""
         prepared = getattr(x, "prepared", None)
+        if isinstance(prepared, PendingIndex):
+            # started ahead of this forward (prepare(wait=False)) and parked at a host read: finish it here, on its own stream
+            while prepared.done is None:
+                yield "sync"
+                prepared.step()
+            prepared = prepared.done
         if prepared is not None:
             # built ahead of this forward on the index stream (prepare()): wait for it, and tell the allocator this stream uses it
             z, x0 = prepared.take(torch.cuda.current_stream() if x.F.is_cuda else None)
@@ -318,21 +324,28 @@ class SPVCNN(nn.Module):
                 voxel_index(cm, s_, z, n)
         return z, x0
 
-    def prepare(self, x):
+    def prepare(self, x, ready=None, wait=True):
         """Build the coordinate structures of batch `x` (a SparseTensor as the forward takes it) NOW, on a stream of their own, and
         hang them on `x`; the forward that later receives `x` starts at the first convolution.  Meant to be called for batch i+1
-        while step i is in flight (trainer.TrainStep(next_batch=...)): the index build is a chain of ~230 small kernels with six
-        host reads, and inside the forward each read waits for everything queued before it -- the previous step's backward."""
+        while step i is in flight (trainer.TrainStep(next_batch=...)): inside the forward each host read of the build waits for
+        everything queued before it -- the previous step's backward.
+        `ready`: an event after which the batch's tensors are valid (default: all work queued on the current stream so far).
+        `wait=False`: issue the build up to its FIRST host read only and return without blocking (the one-pass level build: the sort
+        and the level sizes on their way to the host); the forward resumes it from there.  The caller's thread never waits for the
+        GPU in this form, which is what the training loop wants while the backward is still executing."""
         if getattr(x, "prepared", None) is not None or not x.F.is_cuda:
             return x
         with torch.cuda.device(x.F.device):      # the current device is per thread (prepare may run on a helper thread)
             s_idx = _index_stream(x.F.device)
-            s_idx.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.device(x.F.device), torch.cuda.stream(s_idx), torch.set_grad_enabled(self.training):   # training: also the backward's sorted segments
-            z, x0 = drain(self._index_steps(x, ahead=True))
-            ev = torch.cuda.Event()
-            ev.record()
-        x.prepared = PreparedIndex(z, x0, ev)
+            if ready is not None:
+                s_idx.wait_event(ready)          # the batch was valid at `ready`: do not queue behind what the caller issued since
+            else:
+                s_idx.wait_stream(torch.cuda.current_stream())
+        pending = PendingIndex(self._index_steps(x, ahead=True), s_idx, x.F.device, self.training)   # training: also the backward's sorted segments
+        finished = pending.step()
+        while wait and not finished:
+            finished = pending.step()
+        x.prepared = pending.done if finished else pending
         return x
 
     def forward(self, x):

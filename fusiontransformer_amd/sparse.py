@@ -181,11 +181,17 @@ class HostRead:
     """A few device integers on their way to the host: the copy is queued behind the kernels that produce
     them when the object is made, `value()` waits for that copy only."""
 
+    latest = None      # the read made last on this thread of issue (PendingIndex looks at it to see what a parked build waits for)
+
     def __init__(self, dev: torch.Tensor):
         self.host = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=True)
         self.host.copy_(dev, non_blocking=True)
         self.event = torch.cuda.Event()
         self.event.record()
+        HostRead.latest = self
+
+    def ready(self):
+        return self.event.query()
 
     def values(self):
         self.event.synchronize()
@@ -254,6 +260,36 @@ class PreparedIndex:
         return self.z, self.x0
 
 
+class PendingIndex:
+    """An index build in flight on the index stream: a `*_steps` generator that has been issued up to one of its host reads.  step()
+    resumes it -- blocking on that read, then issuing up to the next one -- with the index stream, the device and the grad mode of the
+    build in force for exactly the duration of the call (a generator suspended inside a `with torch.cuda.stream(...)` block would leave
+    that stream current for its caller).  `done` is the PreparedIndex once the build has been issued to its end."""
+
+    def __init__(self, steps, stream, device, grad):
+        self.steps, self.stream, self.device, self.grad = steps, stream, device, grad
+        self.done = None
+        self.read = None       # the HostRead the build is parked on
+
+    def ready(self):
+        """True when step() would not block: the read the build is parked on has arrived."""
+        return self.done is None and self.read is not None and self.read.ready()
+
+    def step(self):
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream), torch.set_grad_enabled(self.grad):
+            try:
+                HostRead.latest = None
+                next(self.steps)
+                self.read = HostRead.latest
+                return False
+            except StopIteration as fin:
+                z, x0 = fin.value
+                ev = torch.cuda.Event()
+                ev.record()
+                self.done = PreparedIndex(z, x0, ev)
+                return True
+
+
 class SparseTensor:
     def __init__(self, feats, coords, stride=1):
         self.F = feats
@@ -262,7 +298,7 @@ class SparseTensor:
         self.coord_maps = {}
         self.kernel_maps = {}
         self.cm = None  # CoordinateManager, attached by initial_voxelize
-        self.prepared = None  # PreparedIndex, attached by SPVCNN.prepare (coordinate structures built ahead of the forward)
+        self.prepared = None  # PreparedIndex / PendingIndex, attached by SPVCNN.prepare (coordinate structures built ahead of the forward)
 
     def check(self):
         if self.s not in self.coord_maps:

@@ -76,15 +76,26 @@ class TrainStep:
         self.metrics = metrics or ()
         self.grad_reducer = grad_reducer
         self.fused_loss = True
+        self.prefetch_wait = False     # next_batch: start its index build without blocking this thread (SPVCNN.prepare(wait=False))
+        self.prefetch_budget_ms = float(os.environ.get("FTX_PREFETCH_BUDGET_MS", "1.5"))   # ... then poll its host reads this long at most
+        self._prefetch_misses = self._prefetch_pause = 0
         self.last = {}
 
     def __call__(self, data_batch, next_batch=None):
-        """One training step on `data_batch`.  `next_batch` (optional): the batch of the FOLLOWING step; its coordinate structures are
-        built while this step's backward runs (models/_fusion_common.prepare_batch), so the next forward starts at the first
-        convolution.  Measured on MI355X this does NOT pay inside the training loop (batch 4: 128.8 frames/s against 139.7 without;
-        the six host reads of the build then wait behind the backward's kernels instead of behind the previous step's tail, and a
-        helper thread for them, 130.4, contends for the interpreter), so bench.py leaves it off; the entry point is for callers that
-        own an idle moment -- a data-loading worker, an evaluation loop that overlaps the build with the metric."""
+        """One training step on `data_batch`.  `next_batch` (optional): the batch of the FOLLOWING step.  Its index build (voxel sets of the
+        five levels, kernel maps, point <-> voxel indices: ~230 small kernels and two host reads, models/_fusion_common.prepare_batch)
+        is started on a third stream as soon as this step's backward has been issued, without blocking this thread; after the
+        optimizer has been issued the build's reads are polled for at most `prefetch_budget_ms` and every part whose sizes have arrived
+        is issued too; what is left is finished by the next forward.  The chain of small dependent kernels then runs BESIDE this step's
+        backward instead of after it.  Same kernels and results either way (tests/test_model_gpu.py).  `prefetch_wait=True` builds
+        everything with blocking reads (for a caller that owns an idle moment: a data-loading worker, an evaluation loop)."""
+        ready = None
+        if next_batch is not None and not self.prefetch_wait and self._prefetch_pause > 0:
+            self._prefetch_pause -= 1        # the polls kept running out (large batches, see below): this step builds nothing ahead
+            next_batch = None
+        if next_batch is not None and torch.cuda.is_available():
+            ready = torch.cuda.Event()       # whatever produced next_batch was queued before this point: its index build may start
+            ready.record()                   # here and run beside this step, not behind it
         if self.grad_reducer is not None:
             self.grad_reducer.begin_step()   # zeroes the flat gradient buckets (p.grad are views into them)
         else:
@@ -109,9 +120,20 @@ class TrainStep:
         (loss_2d + loss_3d).backward()
         if next_batch is not None:
             from .models._fusion_common import prepare_batch
-            prepare_batch(self.model, next_batch)
+            prepare_batch(self.model, next_batch, ready=ready, wait=self.prefetch_wait)
         if self.grad_reducer is not None:
             self.grad_reducer.finish()
         self.optimizer.step()
+        if next_batch is not None and not self.prefetch_wait:
+            # Small batches: the build's host reads arrive within a fraction of a millisecond, so a short bounded poll gets the whole
+            # build issued before the next forward starts (batch 1: 14.9 -> 13.8 ms per step).  Large batches: they do not -- the small
+            # index kernels sit behind the backward's big ones -- and both the poll (batch 4: +1.1 ms) and the early start (+0.3 ms)
+            # cost more than they give: after two polls in a row that ran out, the next 256 steps build their index inside their own
+            # forward, then the prefetch is tried again.
+            from .models._fusion_common import advance_prepared
+            complete = advance_prepared(next_batch, self.prefetch_budget_ms)
+            self._prefetch_misses = 0 if complete else self._prefetch_misses + 1
+            if self._prefetch_misses >= 2:
+                self._prefetch_pause, self._prefetch_misses = 256, 0
         self.last = {"loss_2d": loss_2d.detach(), "loss_3d": loss_3d.detach()}
         return preds

@@ -271,14 +271,17 @@ def test_index_built_ahead_is_bit_identical_to_index_built_in_the_forward():
     cfg, oracle, model, _ = _pair("middle", seed=6)
     batches = [make_batch([8, 9], max_points=3000), make_batch([10], max_points=2500)]
 
-    def run(prepared, train):
+    def run(prepared, train, wait=True):
         model.train(train)
         outs = []
         for b in batches:
             pin = product_inputs(b)
             if prepared:
-                prepare_batch(model, pin)
+                prepare_batch(model, pin, wait=wait)
                 assert pin["lidar"].prepared is not None
+                if not wait:       # parked at its first host read; the forward finishes it
+                    from fusiontransformer_amd.sparse import PendingIndex
+                    assert isinstance(pin["lidar"].prepared, PendingIndex) and pin["lidar"].prepared.done is None
             model.zero_grad(set_to_none=True)
             torch.manual_seed(0)
             with torch.set_grad_enabled(train):
@@ -293,13 +296,15 @@ def test_index_built_ahead_is_bit_identical_to_index_built_in_the_forward():
         return outs
 
     for train in (True, False):
-        a, b = run(False, train), run(True, train)
-        for (oa, ga), (ob, gb) in zip(a, b):
-            for k in oa:
-                assert torch.equal(oa[k], ob[k]), (train, k)
-            assert ga.keys() == gb.keys()
-            for n in ga:
-                assert torch.equal(ga[n], gb[n]), (train, n)
+        a = run(False, train)
+        for wait in (True, False):
+            b = run(True, train, wait)
+            for (oa, ga), (ob, gb) in zip(a, b):
+                for k in oa:
+                    assert torch.equal(oa[k], ob[k]), (train, wait, k)
+                assert ga.keys() == gb.keys()
+                for n in ga:
+                    assert torch.equal(ga[n], gb[n]), (train, wait, n)
 
     def three_steps(prefetch):
         cfg2, _, m, _ = _pair("middle", seed=7)
@@ -309,6 +314,8 @@ def test_index_built_ahead_is_bit_identical_to_index_built_in_the_forward():
         for i in range(3):
             torch.manual_seed(i)
             step(pins[i % 2], pins[(i + 1) % 2] if prefetch else None)
+            if prefetch:   # small batches: the bounded poll gets the whole build issued before the step returns, and stays switched on
+                assert pins[(i + 1) % 2]["lidar"].prepared is not None and step._prefetch_pause == 0
         torch.cuda.synchronize()
         return {n: p.detach().clone() for n, p in m.named_parameters()}
 
