@@ -500,6 +500,7 @@ def main():
             # secondary figure, outside the timed region above: the literal BASELINE configs[1] workload (ONE frame per step)
             ones = [build_inputs(cfg, 1, args.shape, rank, device, cycle=c)[1] for c in range(max(1, args.cycle))]
             one = ones[0]
+            step.reset_prefetch()      # the self-pausing index prefetch learnt its setting on the batches above
             for i in range(4):
                 step(ones[i % len(ones)], nxt(ones, i))
             torch.cuda.synchronize()

@@ -81,6 +81,10 @@ class TrainStep:
         self._prefetch_misses = self._prefetch_pause = 0
         self.last = {}
 
+    def reset_prefetch(self):
+        """Forget what the self-pausing index prefetch learnt (call when the batch size or shape of the stream of batches changes)."""
+        self._prefetch_misses = self._prefetch_pause = 0
+
     def __call__(self, data_batch, next_batch=None):
         """One training step on `data_batch`.  `next_batch` (optional): the batch of the FOLLOWING step.  Its index build (voxel sets of the
         five levels, kernel maps, point <-> voxel indices: ~230 small kernels and two host reads, models/_fusion_common.prepare_batch)
