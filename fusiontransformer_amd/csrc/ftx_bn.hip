@@ -104,11 +104,11 @@ extern "C" int ftx_stream_scratch_release(void *stream) {
 }
 
 // Grid of the statistics passes.  They stream 1-3 row matrices once and are bound by loads in flight, not by bytes: at 128 rows per
-// block the 81k-row level ran 635 blocks (2.5 per CU) and reached 1.7 TB/s; FTX_BN_ROWS / FTX_BN_MAX_BLOCKS keep the knobs measurable.
+// block the 81k-row level ran 635 blocks (2.5 per CU) and reached 1.7 TB/s.  48 rows per block, at most 2048 blocks: constants, because
+// the grid fixes the summation tree and with it the bits of the statistics (sweeps: DESIGN.md section 5, rounds 2 and 3).
 static int bn_blocks(int64_t n) {
-  static const int rows = getenv("FTX_BN_ROWS") ? atoi(getenv("FTX_BN_ROWS")) : 48;
-  static const int maxb = getenv("FTX_BN_MAX_BLOCKS") ? atoi(getenv("FTX_BN_MAX_BLOCKS")) : 2048;
-  int64_t b = ceil_div(n, rows > 0 ? rows : 48);
+  constexpr int rows = 48, maxb = 2048;
+  int64_t b = ceil_div(n, rows);
   if (b > maxb) b = maxb;
   if (b > LB_GROUP * LB_MAX_GROUPS) b = LB_GROUP * LB_MAX_GROUPS;
   if (b < 1) b = 1;

@@ -210,11 +210,9 @@ __global__ __launch_bounds__(64 * OS_WAVES) void spconv_ostat_kernel(const float
 namespace {
 template <int CA, int CO16, bool WT>
 int os_launch(unsigned grid, hipStream_t st, const float *A, int64_t rows_a, const int32_t *nbr, int64_t n_out, const float *W, int flip, int kvol,
-              float *out, double *part, StreamScratch sc, int waves) {
-  if (waves == 8)
-    spconv_ostat_kernel<CA, CO16, WT, 8><<<grid, 512, 0, st>>>(A, rows_a, nbr, n_out, W, flip, kvol, out, part, sc);
-  else
-    spconv_ostat_kernel<CA, CO16, WT, 4><<<grid, 256, 0, st>>>(A, rows_a, nbr, n_out, W, flip, kvol, out, part, sc);
+              float *out, double *part, StreamScratch sc) {
+  // 4 waves per block; 8 (512 threads, template argument OS_WAVES) measured the same (tools/probes/ostat_variants/README.md)
+  spconv_ostat_kernel<CA, CO16, WT, 4><<<grid, 256, 0, st>>>(A, rows_a, nbr, n_out, W, flip, kvol, out, part, sc);
   return FTX_OK;
 }
 }  // namespace
@@ -252,9 +250,7 @@ extern "C" int ftx_spconv_ostat(const float *A, int64_t rows_a, const int32_t *n
   }
   const unsigned grid = (unsigned)blocks;
   int rc = FTX_OK;
-  static const int waves_env = getenv("FTX_OSTAT_WAVES") ? atoi(getenv("FTX_OSTAT_WAVES")) : 0;   // tuning aid only: results do not depend on it
-  const int waves = waves_env == 4 || waves_env == 8 ? waves_env : 4;
-#define OS_CASE(CA_, CO16_, WT_) rc = os_launch<CA_, CO16_, WT_>(grid, st, A, rows_a, nbr, n_out, W, flip, kvol, out, part, sc, waves)
+#define OS_CASE(CA_, CO16_, WT_) rc = os_launch<CA_, CO16_, WT_>(grid, st, A, rows_a, nbr, n_out, W, flip, kvol, out, part, sc)
   const int co16 = co / 16;
   if (ca == 4) OS_CASE(4, 2, false);
   else if (ca == 32 && co16 == 2 && !w_transposed) OS_CASE(32, 2, false);
