@@ -365,9 +365,14 @@ static void launch_pairs_gemm(int nt, dim3 grid, hipStream_t st, const float *A,
 // One pair-GEMM kernel ships.  The LDS-DMA, producer / consumer and bf16x3 variants of rounds 1-2 each tied or lost against it
 // (DESIGN.md section 8); their sources live under tools/probes/spconv_variants/ and are not part of libftx.so.  Nothing in this file
 // is selected by process-wide mutable state or by a device query: tile shapes and workspace sizes are functions of the arguments.
-static int gemm_nt(int co) {
+// 32-column tiles per block as a function of the arguments: 128 columns per block where there are enough pair tiles to fill the chip,
+// 64 where there are not (the two deepest levels: 159-445 tiles -- 372 blocks of 128 columns took 42.0 us on the 256 -> 256 layer of
+// level 16, 744 blocks of 64 take 34.5; with 472 blocks and more the wider tile wins by 2-5 %, it reads every gathered row once).
+// A column split changes no sum: the results are the same bits either way.
+static int gemm_nt(int co, int64_t row_tiles) {
   int nt = co >= 128 ? 4 : (co + 31) / 32;
   if (co > 128 && co % 96 == 0 && co % 128 != 0) nt = 3;
+  if (nt == 4 && row_tiles * ceil_div(co, 128) <= 400) nt = 2;
   return nt;
 }
 
@@ -381,8 +386,8 @@ extern "C" int ftx_spconv_pairs_gemm(const float *A, int64_t rows_a, const int32
   if (n_pairs == 0) return FTX_OK;
   FTX_REQUIRE(A && gather && W && koff && tmp && rows_a >= 1, "ftx_spconv_pairs_gemm: null pointer or empty operand");
   hipStream_t st = (hipStream_t)stream;
-  const int nt = gemm_nt(co);
   const unsigned tiles_ub = (unsigned)(ceil_div(n_pairs, TILE_P) + kvol);  // sum_k ceil(cnt_k/tile) <= P/tile + kvol
+  const int nt = gemm_nt(co, tiles_ub);
   dim3 grid(tiles_ub, (unsigned)ceil_div(co, 32 * nt));
   launch_pairs_gemm<1>(nt, grid, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, tmp, nullptr, 0);
   return check_launch("ftx_spconv_pairs_gemm");
@@ -400,7 +405,7 @@ extern "C" int ftx_spconv_pairs_gemm_scatter(const float *A, int64_t rows_a, con
   if (n_pairs == 0) return FTX_OK;
   FTX_REQUIRE(A && gather && scatter && W && koff && out && rows_a >= 1, "ftx_spconv_pairs_gemm_scatter: null pointer or empty operand");
   hipStream_t st = (hipStream_t)stream;
-  const int nt = gemm_nt(co);
+  const int nt = gemm_nt(co, ceil_div(n_pairs, TILE_P) + kvol);
   dim3 grid((unsigned)(ceil_div(n_pairs, TILE_P) + kvol), (unsigned)ceil_div(co, 32 * nt));
   launch_pairs_gemm<1>(nt, grid, st, A, rows_a, gather, W, w_transposed, koff, ca, co, kvol, out, nullptr, 0, scatter, rows_out);
   return check_launch("ftx_spconv_pairs_gemm_scatter");
@@ -416,7 +421,7 @@ extern "C" int ftx_rows_gemm(const float *A, int64_t n, const float *W, int32_t 
   if (n == 0) return FTX_OK;
   FTX_REQUIRE(A && W && out, "ftx_rows_gemm: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  const int nt = gemm_nt(co);
+  const int nt = gemm_nt(co, ceil_div(n, TILE_P));
   dim3 grid((unsigned)ceil_div(n, TILE_P), (unsigned)ceil_div(co, 32 * nt));
   launch_pairs_gemm<1>(nt, grid, st, A, n, nullptr, W, w_transposed, nullptr, ca, co, 1, out, bias, n);
   return check_launch("ftx_rows_gemm");
