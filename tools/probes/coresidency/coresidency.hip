@@ -38,7 +38,9 @@ __global__ __launch_bounds__(256) void mfma_kernel(float *out, int iters) {
   out[blockIdx.x * 256 + tid] = s;
 }
 
+template <int PRIO>
 __global__ void stream_kernel(const float4 *a, const float4 *b, const float4 *c, float4 *o, size_t n) {
+  if (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);   // raise this wave's issue priority over co-resident waves (the MFMA kernel's)
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float4 x = a[i], y = b[i], z = c[i];
     o[i] = make_float4(x.x + y.x * z.x, x.y + y.y * z.y, x.z + y.z * z.z, x.w + y.w * z.w);
@@ -47,7 +49,7 @@ __global__ void stream_kernel(const float4 *a, const float4 *b, const float4 *c,
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
-template <int NT>
+template <int NT, int PRIO>
 int run(int bpc, int iters) {
   hipStream_t sa, sb;
   CK(hipStreamCreate(&sa)); CK(hipStreamCreate(&sb));
@@ -60,7 +62,7 @@ int run(int bpc, int iters) {
   for (auto &x : ev) CK(hipEventCreate(&x));
   const int chain = 60;
   auto A = [&]() { mfma_kernel<NT><<<256 * bpc, 256, 0, sa>>>(out, iters); };
-  auto B = [&]() { for (int i = 0; i < chain; ++i) stream_kernel<<<2048, 256, 0, sb>>>(a, b, c, o, n4); };
+  auto B = [&]() { for (int i = 0; i < chain; ++i) stream_kernel<PRIO><<<2048, 256, 0, sb>>>(a, b, c, o, n4); };
   A(); B(); CK(hipDeviceSynchronize());
   float ta, tb, tab_a, tab_b;
   CK(hipEventRecord(ev[0], sa)); A(); CK(hipEventRecord(ev[1], sa)); CK(hipDeviceSynchronize()); CK(hipEventElapsedTime(&ta, ev[0], ev[1]));
@@ -69,16 +71,20 @@ int run(int bpc, int iters) {
   CK(hipDeviceSynchronize());
   CK(hipEventElapsedTime(&tab_a, ev[0], ev[1])); CK(hipEventElapsedTime(&tab_b, ev[2], ev[3]));
   const double flops = 2.0 * 32 * 32 * 2 * 16 * NT * 4.0 * iters * 256 * bpc;
-  printf("A: %d accumulators, %d block(s)/CU: A alone %.2f ms (%.0f TFLOP/s) | B alone %.2f ms (%.0f GB/s) | together: A %.2f ms, B %.2f ms  (sum alone %.2f, max alone %.2f)\n",
-         NT, bpc, ta, flops / ta / 1e9, tb, chain * 4.0 * 32 * (1 << 20) / tb / 1e6, tab_a, tab_b, ta + tb, ta > tb ? ta : tb);
+  printf("B at s_setprio %d | A: %d accumulators, %d block(s)/CU: A alone %.2f ms (%.0f TFLOP/s) | B alone %.2f ms (%.0f GB/s) | together: A %.2f ms, B %.2f ms  (sum alone %.2f, max alone %.2f)\n",
+         PRIO, NT, bpc, ta, flops / ta / 1e9, tb, chain * 4.0 * 32 * (1 << 20) / tb / 1e6, tab_a, tab_b, ta + tb, ta > tb ? ta : tb);
   return 0;
 }
 
 int main() {
-  if (run<4>(1, 6000)) return 1;
-  if (run<4>(2, 3000)) return 1;
-  if (run<4>(4, 1500)) return 1;
-  if (run<8>(1, 3000)) return 1;
-  if (run<8>(2, 1500)) return 1;
+  if (run<4, 0>(1, 6000)) return 1;
+  if (run<4, 0>(2, 3000)) return 1;
+  if (run<4, 0>(4, 1500)) return 1;
+  if (run<8, 0>(1, 3000)) return 1;
+  if (run<8, 0>(2, 1500)) return 1;
+  if (run<4, 3>(1, 6000)) return 1;
+  if (run<4, 3>(2, 3000)) return 1;
+  if (run<4, 3>(4, 1500)) return 1;
+  if (run<8, 3>(2, 1500)) return 1;
   return 0;
 }
