@@ -122,11 +122,11 @@ class TrainStep:
                 for m in self.metrics:
                     m.update_dict(preds, data_batch)
         (loss_2d + loss_3d).backward()
+        if self.grad_reducer is not None:
+            self.grad_reducer.finish()       # the remaining gradient buckets go out before anything else is issued
         if next_batch is not None:
             from .models._fusion_common import prepare_batch
             prepare_batch(self.model, next_batch, ready=ready, wait=self.prefetch_wait)
-        if self.grad_reducer is not None:
-            self.grad_reducer.finish()
         self.optimizer.step()
         if next_batch is not None and not self.prefetch_wait:
             # Small batches: the build's host reads arrive within a fraction of a millisecond, so a short bounded poll gets the whole
