@@ -62,11 +62,11 @@ def init_process_group(backend=None, force=False):
 
 
 class _Bucket:
-    __slots__ = ("params", "flat", "views", "work", "launched", "tail_seen", "hold")
+    __slots__ = ("params", "flat", "views", "work", "launched", "tail_seen", "hold", "events")
 
     def __init__(self, params, flat, views):
         self.params, self.flat, self.views = params, flat, views
-        self.work, self.launched, self.tail_seen, self.hold = None, False, False, None
+        self.work, self.launched, self.tail_seen, self.hold, self.events = None, False, False, None, None
 
 
 class GradReducer:
@@ -162,7 +162,7 @@ class GradReducer:
             # one hook per bucket, on the parameter whose gradient arrived last in step 0
             self._handles = [b.params[-1].register_post_accumulate_grad_hook(lambda p, i=i: self._on_bucket_tail(i)) for i, b in enumerate(self.buckets)]
         for b in self.buckets:
-            b.work, b.launched, b.tail_seen, b.hold = None, False, False, None
+            b.work, b.launched, b.tail_seen, b.hold, b.events = None, False, False, None, None
         for p in self.params:
             p.grad = None    # autograd then MOVES each gradient into place (no add kernel per parameter); _launch packs the bucket
         self.next_to_launch = 0
@@ -203,6 +203,14 @@ class GradReducer:
             b.hold = src
         return True
 
+    def _mark(self, b):
+        """One event per accumulating stream, recorded NOW: everything that produced this bucket's gradients has been issued."""
+        b.events = []
+        for st in self._streams.values():
+            ev = torch.cuda.Event()
+            ev.record(st)
+            b.events.append(ev)
+
     def _launch(self, b, early=False):
         """Everything here runs on the autograd thread when early=True, between two backward nodes: host time spent here delays the
         issue of the rest of the backward one to one (measured: 7 early launches of ~0.4 ms each cost MORE than not overlapping the
@@ -213,11 +221,11 @@ class GradReducer:
         if b.flat.is_cuda:
             comm = self._comm_stream(b.flat.device)
             with torch.cuda.stream(comm):
-                # order the exchange after everything queued so far on every stream that accumulates gradients (one event per stream,
-                # recorded now: later than strictly needed, but no event per gradient and nothing blocks compute)
-                for st in self._streams.values():
-                    ev = torch.cuda.Event()
-                    ev.record(st)
+                # order the exchange after everything that had been queued on every gradient-accumulating stream when the bucket's
+                # tail arrived (_mark: one event per stream, nothing blocks compute)
+                if b.events is None:
+                    self._mark(b)
+                for ev in b.events:
                     comm.wait_event(ev)
                 if not self._pack(b, early):
                     return False
@@ -234,9 +242,10 @@ class GradReducer:
         b.launched = True
         return True
 
-    def _launch_ready_prefix(self):
-        """Buckets go out strictly in bucket order on every rank (collectives are matched by issue order)."""
-        while self.next_to_launch < len(self.buckets):
+    def _launch_ready_prefix(self, upto):
+        """Buckets go out strictly in bucket order on every rank (collectives are matched by issue order); `upto`: first bucket NOT to
+        launch now."""
+        while self.next_to_launch < min(upto, len(self.buckets)):
             b = self.buckets[self.next_to_launch]
             if not b.tail_seen or not self._launch(b, early=True):
                 return
@@ -251,11 +260,20 @@ class GradReducer:
             self._streams[st.cuda_stream] = st
 
     def _on_bucket_tail(self, i):
+        """Bucket i is complete on the host side: mark it (events on the accumulating streams) and launch the buckets BEFORE it.
+        One bucket of delay on purpose.  The exchange stream's wait for a bucket's events is a barrier in a hardware queue; with four
+        hardware queues for six HIP streams it shares that queue with a compute stream (measured: the exchange stream and the image
+        branch's), and while the barrier is pending -- the host issues the backward several milliseconds ahead of the GPU -- that
+        stream's kernels queue up behind it: +2.5 ms per step on one GPU with no byte moved.  Waiting for the PREVIOUS bucket's
+        events, which are (nearly) reached by the time the next tail arrives, costs +0.6 ms (tools/probes/reducer_ab6.sh)."""
         t0 = time.perf_counter()
-        self.buckets[i].tail_seen = True
+        b = self.buckets[i]
+        b.tail_seen = True
+        if b.flat.is_cuda and self.active:
+            self._mark(b)
         if os.environ.get("FTX_REDUCER_LATE") != "1":       # measurement aid: 1 = nothing goes out before finish()
             before = self.next_to_launch
-            self._launch_ready_prefix()
+            self._launch_ready_prefix(i if os.environ.get("FTX_REDUCER_EAGER") != "1" else i + 1)   # aid: 1 = round 3's launch at the tail
             self.hook_stats["early_launches"] += self.next_to_launch - before
             self.hook_stats["deferred"] += int(self.next_to_launch == before)
         self.hook_stats["calls"] += 1
