@@ -452,7 +452,7 @@ def main():
         out["rccl_ranks"] = (world if (_d.is_initialized() and _d.get_backend() == "nccl") else 0)
         out["multi_gpu"] = ("measured: %d ranks over RCCL" % world) if (world > 1 and out["rccl_ranks"] > 1) else "unmeasured in this run (one GPU)"
         out["collectives"] = ("none (single process, no process group)" if reducer is None else
-                              "%s backend, %d rank(s), %d flat buckets of <= %d MB, async all-reduce on an exchange stream, issued from the autograd hook of each bucket's last gradient%s"
+                              "%s backend, %d rank(s), %d flat buckets of <= %d MB, async all-reduce on an exchange stream, each bucket issued from the autograd hook of the NEXT bucket's last gradient (the last one after the backward)%s"
                               % (_d.get_backend(), world, len(reducer.buckets), reducer.bucket_bytes >> 20, " (forced at world size 1)" if world == 1 else ""))
         if roof is not None and args.attn == "ftx" and not args.no_attention_roofline:
             # The ViT trunk replays as HIP graphs, whose kernels cannot be bracketed by events from the host; the attention kernels are
