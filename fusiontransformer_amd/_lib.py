@@ -33,6 +33,7 @@ SIGNATURES = {
     "ftx_count": (C.c_int, [_vp, _i64, _vp, _i64, _vp]),
     "ftx_unique_workspace_bytes": (_sz, [_i64]),
     "ftx_unique_sorted": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ftx_rotate_points": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "ftx_sorted_rank": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "ftx_downsample_coords": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "ftx_gather_coords": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),

@@ -276,6 +276,35 @@ extern "C" int ftx_sorted_rank(const int64_t *sorted, const int32_t *n_sorted, i
   return check_launch("ftx_sorted_rank");
 }
 
+// ---------------------------------------------------------------- 3-D augmentation of the dataset side (f1)
+// out[i,:] = points[i,:] . R for a 3x3 R, with the rounding of `points.dot(rot_matrix)` in the reference
+// (data/utils/augmentation_3d.py:41): the sgemm behind numpy's dot walks K = 3 with one fused multiply-add per step,
+// t = x*r0j; t = fma(y, r1j, t); t = fma(z, r2j, t)  (checked against numpy on 600 000 values: 0 differences; a plain
+// mul / add chain differs in 23 % of them, and a voxel index can change with the last bit).
+struct Rot3 { float r[9]; };
+__global__ void rotate_points_kernel(const float *__restrict__ p, int64_t n, Rot3 R, float *__restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float x = p[3 * i], y = p[3 * i + 1], z = p[3 * i + 2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float t = __fmul_rn(x, R.r[j]);
+      t = __fmaf_rn(y, R.r[3 + j], t);
+      t = __fmaf_rn(z, R.r[6 + j], t);
+      out[3 * i + j] = t;
+    }
+  }
+}
+
+extern "C" int ftx_rotate_points(const float *points, int64_t n, const float *rot_host, float *out, void *stream) {
+  FTX_REQUIRE(n >= 0, "ftx_rotate_points: n < 0");
+  if (n == 0) return FTX_OK;
+  FTX_REQUIRE(points && rot_host && out, "ftx_rotate_points: null pointer");
+  Rot3 R;
+  for (int i = 0; i < 9; ++i) R.r[i] = rot_host[i];
+  rotate_points_kernel<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(points, n, R, out);
+  return check_launch("ftx_rotate_points");
+}
+
 // ---------------------------------------------------------------- downsample / gather of coordinate rows
 __device__ inline int floor_div(int a, int b) {
   int q = a / b;

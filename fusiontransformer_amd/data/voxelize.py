@@ -27,9 +27,13 @@ from ..sparse import HostRead, SparseTensor
 _SENTINEL = (1 << 60) - 1      # sorts after every real key (keys < full_scale^3 <= 2^36); libftx sorts bits [0, 60)
 
 
-def _scale_cast_mask(points: torch.Tensor, scale: int, full_scale: int):
-    coords = points * float(scale)                       # float32 multiply, as numpy does
-    coords = coords - coords.min(0).values               # translate to the positive octant (augmentation_3d.py:41-44)
+def _scale_cast_mask(points: torch.Tensor, scale: int, full_scale: int, aug=None):
+    if aug is not None:                                  # (rot, transl_u) from data.augment.draw_augmentation_3d
+        from .augment import augment_and_scale_3d
+        coords = augment_and_scale_3d(points, scale, full_scale, aug[0], aug[1])
+    else:
+        coords = points * float(scale)                   # float32 multiply, as numpy does
+        coords = coords - coords.min(0).values           # translate to the positive octant (augmentation_3d.py:41-44)
     ci = coords.to(torch.int64)                          # astype(np.int64): truncation
     valid = (ci.min(1).values >= 0) & (ci.max(1).values < full_scale)
     key = (ci[:, 0] * full_scale + ci[:, 1]) * full_scale + ci[:, 2]
@@ -49,8 +53,11 @@ def points_to_voxels(points: torch.Tensor, scale: int = 20, full_scale: int = 40
     return ci[keep], keep
 
 
-def voxelize_frames(frames, scale: int = 20, full_scale: int = 4096):
+def voxelize_frames(frames, scale: int = 20, full_scale: int = 4096, augment=None):
     """The voxelisation half of SemanticKITTISCN.__getitem__ for a list of frames, on the device.
+
+    `augment`: optional list with one `(rot, transl_u)` pair per frame (data.augment.draw_augmentation_3d: the reference's 3-D
+    augmentation with its random draws made on the host in the reference's order); None = no augmentation, this fork's default.
 
     frames: list of dicts with device tensors `points` (N,3) f32, `feats` (N,C) f32, `seg_label` (N,) int64,
     `img_indices` (N,2) int64 (row, col) and anything else (`img`, `seq`, `filename`), which is passed through.
@@ -60,7 +67,9 @@ def voxelize_frames(frames, scale: int = 20, full_scale: int = 4096):
     All kernels of all frames are queued first; the per-frame voxel counts (and out-of-range point counts) then come back in ONE
     pinned-memory read."""
     queued = []
-    for f in frames:
+    if augment is not None and len(augment) != len(frames):
+        raise ValueError("voxelize_frames: `augment` needs one (rot, transl_u) pair per frame")
+    for fi, f in enumerate(frames):
         pts = f["points"]
         if not pts.is_cuda or pts.dtype != torch.float32 or pts.dim() != 2 or pts.shape[1] != 3:
             raise ValueError("voxelize_frames: `points` must be a (N,3) float32 CUDA tensor")
@@ -68,7 +77,7 @@ def voxelize_frames(frames, scale: int = 20, full_scale: int = 4096):
         for k in ("feats", "seg_label", "img_indices"):
             if f[k].shape[0] != n or not f[k].is_cuda:
                 raise ValueError("voxelize_frames: `%s` must be a CUDA tensor with one row per point" % k)
-        ci, valid, key = _scale_cast_mask(pts, scale, full_scale)
+        ci, valid, key = _scale_cast_mask(pts, scale, full_scale, None if augment is None else augment[fi])
         key = torch.where(valid, key, torch.full_like(key, _SENTINEL)).contiguous()   # out-of-range points sort last, as one extra group
         uniq, first, cnt = spf.unique_sorted(key)
         inverse = spf.sorted_rank(uniq, cnt, key)

@@ -243,6 +243,20 @@ def sorted_rank(sorted_keys: torch.Tensor, n_sorted: torch.Tensor, queries: torc
     return rank
 
 
+def rotate_points(points: torch.Tensor, rot) -> torch.Tensor:
+    """points (N,3) float32 @ rot (3,3) float32 (host array) with the rounding of numpy's `points.dot(rot)` (libftx)."""
+    import ctypes
+    import numpy as np
+    L = _lib.load()
+    req(points, F32, "rotate_points points", 2)
+    if points.shape[1] != 3:
+        raise ValueError("rotate_points: points must be (N, 3)")
+    r = np.ascontiguousarray(np.asarray(rot, dtype=np.float32).reshape(9))
+    out = _empty(tuple(points.shape), F32, points)
+    check(L.ftx_rotate_points(ptr(points), points.shape[0], r.ctypes.data_as(ctypes.c_void_p), ptr(out), stream()), "ftx_rotate_points")
+    return out
+
+
 def downsample_coords(coords: torch.Tensor, ratio: int) -> torch.Tensor:
     L = _lib.load()
     req(coords, I32, "downsample coords", 2)

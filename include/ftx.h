@@ -83,6 +83,9 @@ int ftx_unique_sorted(const int64_t *keys, int64_t n, int64_t *uniq, int32_t *fi
 /* rank[i] = position of queries[i] in sorted[0 .. min(*n_sorted, capacity)) (ascending, unique; the count is read ON THE DEVICE), -1 when
  * absent.  On the output of ftx_unique_sorted this is numpy.unique's return_inverse, i.e. the inverse map of torchsparse
  * sparse_quantize(..., return_invs=True) (data/semantic_kitti/semantic_kitti_dataloader.py:231). */
+/* out[i,:] = points[i,:] . R (R: 9 floats, row-major, on the HOST) with the rounding of numpy's float32 `points.dot(rot_matrix)` --
+ * one fused multiply-add per step of K = 3 --: the rotation / flip of data/utils/augmentation_3d.py:22-41 on the device */
+int ftx_rotate_points(const float *points, int64_t n, const float *rot_host, float *out, void *stream);
 int ftx_sorted_rank(const int64_t *sorted, const int32_t *n_sorted, int64_t capacity, const int64_t *queries, int64_t nq, int32_t *rank, void *stream);
 
 /* torchsparse spdownsample coordinate rule: floor(c / ratio) * ratio on x,y,z, b kept.

@@ -801,3 +801,31 @@ def validate_batch(lidar_logit, img_logit, inverse_maps, orig_seg_labels, n_vox,
                     mats[k][index_of[int(g)], index_of[int(p)]] += 1
         left = right
     return [np.concatenate(o) for o in outs], mats
+
+
+# ---------------------------------------------------------------- dataset-side 3-D augmentation
+def augment_and_scale_3d_np(points, scale, full_scale, rot=None, transl_u=None):
+    """data/utils/augmentation_3d.py:22-53 given the random draws (rot: the (3,3) float32 matrix after noise / flips / z rotation,
+    transl_u: the rand(3) of the translation).  Pinned by tests/golden/voxel_coords_augmented.npz (the reference function run here).
+
+    The rounding of `points.dot(rot_matrix)` (:41) is stated explicitly instead of being left to whatever BLAS is linked: one fused
+    multiply-add per step of K = 3, t = x*r0j; t = fma(y, r1j, t); t = fma(z, r2j, t) -- fma(a, b, c) evaluated as
+    float32(float64(a) * float64(b) + float64(c)), exact up to a double rounding that needs a 29-bit coincidence."""
+    points = np.asarray(points, dtype=np.float32)
+    if rot is not None:
+        rot = np.asarray(rot, dtype=np.float32)
+        x, y, z = (points[:, i].astype(np.float64) for i in range(3))
+        cols = []
+        for j in range(3):
+            t = (x * np.float64(rot[0, j])).astype(np.float32)
+            t = (y * np.float64(rot[1, j]) + t.astype(np.float64)).astype(np.float32)
+            t = (z * np.float64(rot[2, j]) + t.astype(np.float64)).astype(np.float32)
+            cols.append(t)
+        points = np.stack(cols, 1)
+    coords = points * np.float32(scale)
+    coords = coords - coords.min(0)
+    if transl_u is not None:
+        room = np.clip(np.float32(full_scale) - coords.max(0) - np.float32(0.001), np.float32(0), None)      # float32 (:50)
+        offset = room.astype(np.float64) * np.asarray(transl_u, dtype=np.float64)
+        coords = (coords.astype(np.float64) + offset).astype(np.float32)                                     # float32 += float64 (:51)
+    return coords

@@ -20,6 +20,8 @@ What is pinned, and by which reference code:
                        modules/SemanticTorchpackTrainer.py:28-32,70-106, on the logits of losses_metric.npz.
   voxel_coords.npz     reference augment_and_scale_3d (data/utils/augmentation_3d.py:4-53) and
                        the int cast / range mask of semantic_kitti_dataloader.py:216-225.
+  voxel_coords_augmented.npz  the same function with its augmentation branch on (noisy rotation, flips, rotation about z,
+                       translation; data/utils/augmentation_3d.py:22-51), numpy.random seeded per case.
   projection.npz       reference DummyDataset.read_calib / select_points_in_frustum and the
                        projection statements of data/semantic_kitti/preprocess.py:54-116 on a
                        synthetic calib file + scan.
@@ -164,6 +166,32 @@ def voxel_coords():
     np.savez_compressed(os.path.join(OUT, "voxel_coords.npz"), points=points, coords_float=coords, coords_int=coords_i, valid=valid)
 
 
+def voxel_coords_augmented():
+    """The augmentation branch of the reference function (noisy rotation, flips, z rotation, translation), seeded through numpy.random
+    as the dataloader leaves it: points, parameters and seed in, float / integer coordinates and the in-range mask out."""
+    from FusionTransformer.data.utils.augmentation_3d import augment_and_scale_3d
+    rng = np.random.default_rng(12)
+    points = (rng.uniform(-1, 1, size=(2500, 3)) * np.array([60, 40, 3])).astype(np.float32)
+    points[:, 0] = np.abs(points[:, 0])
+    cases = {
+        "all": dict(noisy_rot=0.1, flip_x=0.5, flip_y=0.5, rot_z=2 * np.pi, transl=True),      # xmuda-style settings, everything on
+        "kitti": dict(noisy_rot=0.1, flip_x=0.0, flip_y=0.5, rot_z=2 * np.pi, transl=True),    # the commented values of the fork's config
+        "flip_only": dict(noisy_rot=0.0, flip_x=0.5, flip_y=0.0, rot_z=0.0, transl=False),
+        "rot_only": dict(noisy_rot=0.0, flip_x=0.0, flip_y=0.0, rot_z=2 * np.pi, transl=False),
+        "transl_only": dict(noisy_rot=0.0, flip_x=0.0, flip_y=0.0, rot_z=0.0, transl=True),
+    }
+    save = {"points": points, "cases": np.array(list(cases.keys()))}
+    for i, (name, kw) in enumerate(cases.items()):
+        for rep in range(2):
+            seed = 100 + 10 * i + rep
+            np.random.seed(seed)
+            coords = augment_and_scale_3d(points.copy(), 20, 4096, **kw)
+            tag = "%s_%d" % (name, rep)      # the int cast and the range mask (dataloader :220-225) are applied by the tests
+            save.update({tag + "_seed": seed, tag + "_params": np.array([kw["noisy_rot"], kw["flip_x"], kw["flip_y"], kw["rot_z"], float(kw["transl"])]),
+                         tag + "_coords_float": coords})
+    np.savez_compressed(os.path.join(OUT, "voxel_coords_augmented.npz"), **save)
+
+
 def projection():
     from FusionTransformer.data.semantic_kitti.preprocess import DummyDataset
     rng = np.random.default_rng(3)
@@ -255,6 +283,7 @@ if __name__ == "__main__":
     losses_metric()
     losses_torchpack()
     voxel_coords()
+    voxel_coords_augmented()
     projection()
     eval_scatter_back()
     for f in sorted(os.listdir(OUT)):

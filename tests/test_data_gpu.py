@@ -107,3 +107,64 @@ def test_device_collate_equals_host_collate_and_feeds_model_and_eval():
         exp.append(p3[off:off + r["coords"].shape[0]][r["inverse_map"]])
         off += r["coords"].shape[0]
     assert np.array_equal(rd["pred_3d"].cpu().numpy(), np.concatenate(exp))
+
+
+def test_voxelize_frames_with_the_augmentation_branch():
+    """The 3-D augmentation on the device inside voxelize_frames (rotation by libftx, translation in float64 like numpy) against the
+    dataloader's statements with the oracle's restatement of augment_and_scale_3d (itself pinned by the reference function's output,
+    tests/test_golden.py): every key bit for bit, draws made by draw_augmentation_3d from a seeded numpy.random."""
+    from fusiontransformer_amd.data.augment import draw_augmentation_3d
+    from fusiontransformer_amd.data.voxelize import voxelize_frames
+    from oracle import ft_oracle as O
+    raw = [_raw_frame(7, 6000, 11), _raw_frame(8, 3000, 0)]
+    np.random.seed(5)
+    draws = [draw_augmentation_3d(noisy_rot=0.1, flip_x=0.5, flip_y=0.5, rot_z=2 * np.pi, transl=True) for _ in raw]
+    ref = []
+    for f, (rot, u) in zip(raw, draws):
+        g = {k: v.copy() for k, v in f.items()}
+        coords = O.augment_and_scale_3d_np(g["points"], 20, 4096, rot, u).astype(np.int64)
+        valid = (coords.min(1) >= 0) * (coords.max(1) < 4096)
+        vc = coords[valid]
+        key = (vc[:, 0] * 4096 + vc[:, 1]) * 4096 + vc[:, 2]
+        _, inds, inverse = np.unique(key, return_index=True, return_inverse=True)
+        ref.append(dict(voxel_coords=vc, coords=vc[inds], feats=g["feats"][valid][inds], seg_label=g["seg_label"][valid][inds],
+                        img_indices=g["img_indices"][valid][inds], inverse_map=inverse))
+    out = voxelize_frames([_to_device(f) for f in raw], augment=draws)
+    for r, o in zip(ref, out):
+        for k in r:
+            assert np.array_equal(o[k].cpu().numpy(), r[k]), k
+    plain = voxelize_frames([_to_device(f) for f in raw])
+    assert not torch.equal(plain[0]["voxel_coords"], out[0]["voxel_coords"])          # the augmentation really moved the voxels
+
+
+def test_image_side_augmentation_matches_the_dataloader_statements():
+    """Bottom crop + point filter + shift, int cast, left-right flip with the column update, normalisation, HWC -> CHW
+    (semantic_kitti_dataloader.py:166-212, restated in numpy here: that class is not importable -- PARITY UNPINNED)."""
+    from fusiontransformer_amd.data.augment import augment_image, draw_augmentation_2d
+    rng = np.random.default_rng(3)
+    H, W, n = 370, 1226, 5000
+    image = rng.random((H, W, 3)).astype(np.float32)
+    points_img = np.stack([rng.uniform(0, H, n), rng.uniform(0, W, n)], 1).astype(np.float32)
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    for seed, crop, fliplr in ((1, (480, 302), 0.5), (2, (480, 302), 1.0), (3, None, 1.0), (4, None, None)):
+        np.random.seed(seed)
+        box, flip = draw_augmentation_2d((W, H), crop, fliplr)
+        # the dataloader's statements, with the same seed
+        np.random.seed(seed)
+        img, pi, keep = image, points_img.copy(), np.ones(n, dtype=bool)
+        if crop is not None:
+            left = int(np.random.rand() * (W + 1 - crop[0])); right = left + crop[0]; top = H - crop[1]; bottom = H
+            keep = (pi[:, 0] >= top) & (pi[:, 0] < bottom) & (pi[:, 1] >= left) & (pi[:, 1] < right)
+            img = img[top:bottom, left:right]
+            pi = pi[keep]
+            pi[:, 0] -= top
+            pi[:, 1] -= left
+        idx = pi.astype(np.int64)
+        if (fliplr is not None) and (np.random.rand() < fliplr):
+            img = np.ascontiguousarray(np.fliplr(img))
+            idx[:, 1] = img.shape[1] - 1 - idx[:, 1]
+        img = (img - np.asarray(mean, dtype=np.float32)) / np.asarray(std, dtype=np.float32)
+        want = np.moveaxis(img, -1, 0)
+        got_img, got_idx, got_keep = augment_image(torch.from_numpy(image).cuda(), torch.from_numpy(points_img).cuda(), box, flip, (mean, std))
+        assert np.array_equal(got_keep.cpu().numpy(), keep) and np.array_equal(got_idx.cpu().numpy(), idx), seed
+        assert got_img.shape == want.shape and np.array_equal(got_img.cpu().numpy(), want), seed

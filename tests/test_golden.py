@@ -265,3 +265,44 @@ def test_projection_kernel_matches_reference_preprocess():
     assert np.array_equal(d["points"], g["points"][g["keep_idx"]]) and np.array_equal(d["feats"], scan[g["keep_idx"]])
     assert d["seg_label"].dtype == np.int16 and np.array_equal(d["seg_label"], (np.arange(len(scan)) % 20)[g["keep_idx"]])
     assert np.array_equal(d["points_img"], g["points_img"])
+
+
+def _aug_cases():
+    g = load("voxel_coords_augmented.npz")
+    for name in g["cases"]:
+        for rep in range(2):
+            tag = "%s_%d" % (name, rep)
+            noisy_rot, flip_x, flip_y, rot_z, transl = (float(v) for v in g[tag + "_params"])
+            yield tag, g["points"], int(g[tag + "_seed"]), dict(noisy_rot=noisy_rot, flip_x=flip_x, flip_y=flip_y, rot_z=rot_z, transl=bool(transl)), g[tag + "_coords_float"]
+
+
+def test_augmentation_draws_and_cpu_restatement_match_the_reference_function():
+    """draw_augmentation_3d consumes numpy.random in the reference's order (same seed -> same rotation matrix and offset), and the
+    oracle's restatement of the arithmetic -- with the dot product's fused rounding written out -- reproduces the reference function's
+    float coordinates bit for bit, for every augmentation mix of the fixture (data/utils/augmentation_3d.py:4-53)."""
+    from fusiontransformer_amd.data.augment import draw_augmentation_3d
+    n = 0
+    for tag, points, seed, kw, want in _aug_cases():
+        np.random.seed(seed)
+        rot, u = draw_augmentation_3d(**kw)
+        assert (rot is None) == (not (kw["noisy_rot"] > 0 or kw["flip_x"] > 0 or kw["flip_y"] > 0 or kw["rot_z"] > 0)) and (u is None) == (not kw["transl"])
+        got = O.augment_and_scale_3d_np(points.copy(), 20, 4096, rot, u)
+        assert got.dtype == np.float32 and np.array_equal(got, want), tag
+        n += 1
+    assert n == 10
+
+
+@pytest.mark.gpu
+def test_gpu_augmentation_matches_the_reference_function():
+    """fusiontransformer_amd.data.augment.augment_and_scale_3d on the device (rotation by libftx's ftx_rotate_points) against the
+    reference function's output: float coordinates, integer voxel coordinates and the in-range mask bit for bit."""
+    import torch
+    from fusiontransformer_amd.data.augment import augment_and_scale_3d, draw_augmentation_3d
+    for tag, points, seed, kw, want in _aug_cases():
+        np.random.seed(seed)
+        rot, u = draw_augmentation_3d(**kw)
+        got = augment_and_scale_3d(torch.from_numpy(points.copy()).cuda(), 20, 4096, rot, u)
+        assert np.array_equal(got.cpu().numpy(), want), tag
+        ci, wi = got.to(torch.int64).cpu().numpy(), want.astype(np.int64)                     # dataloader :220
+        assert np.array_equal(ci, wi), tag
+        assert np.array_equal((ci.min(1) >= 0) * (ci.max(1) < 4096), (wi.min(1) >= 0) * (wi.max(1) < 4096)), tag
