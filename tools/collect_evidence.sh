@@ -11,6 +11,8 @@ python tools/bench_spconv.py > $O/spconv_layer_micro.txt 2>&1; tail -1 $O/spconv
 python tools/bench_bn.py > $O/bn_layer_micro.txt 2>&1; tail -1 $O/bn_layer_micro.txt
 python tools/probes/eval_throughput.py > $O/eval_throughput.txt 2>&1; tail -2 $O/eval_throughput.txt
 python tools/bench_attn.py > $O/attn_tilings.txt 2>&1; tail -3 $O/attn_tilings.txt
+python tools/probes/loss_time.py > $O/loss_time.txt 2>&1; tail -2 $O/loss_time.txt
+bash tools/probes/reducer_ab6.sh > $O/reducer_one_gpu_cost.txt 2>&1; cat $O/reducer_one_gpu_cost.txt
 # N > 1 code path (bucketed overlapped all-reduce, per-rank batches) rehearsed as 2 ranks on this one GPU over gloo: NOT a scaling number
 FTX_DIST_BACKEND=gloo FTX_FORCE_DEVICE=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
   bench.py --gpus 2 --steps 6 --warmup 3 --no-cpu-baseline > $O/bench_2ranks_one_gpu_gloo.json 2> $O/bench_2ranks.err; tail -c 300 $O/bench_2ranks_one_gpu_gloo.json
@@ -32,6 +34,7 @@ rocprofv3 --kernel-trace --output-format csv -d /tmp/ev_k1 -- python3 $R/bench.p
 python3 $R/tools/step_kernels.py /tmp/ev_k1 > $O/step_kernels_batch1.txt; head -2 $O/step_kernels_batch1.txt
 rocprofv3 --kernel-trace --output-format csv -d /tmp/ev_k4 -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-batch1 --no-nuscenes --no-selfcheck > /dev/null 2>&1
 python3 $R/tools/step_kernels.py /tmp/ev_k4 > $O/step_kernels_batch4.txt; head -2 $O/step_kernels_batch4.txt
+python3 $R/tools/underfilled.py /tmp/ev_k4 12 > $O/underfilled_batch4.txt; head -3 $O/underfilled_batch4.txt
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/ev_f -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch1 --no-nuscenes --no-selfcheck --no-attention-roofline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/ev_w -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch1 --no-nuscenes --no-selfcheck --no-attention-roofline > /dev/null 2>&1
 python3 $R/tools/pmc_hbm.py $(find /tmp/ev_f -name "*counter_collection.csv" | head -1) $(find /tmp/ev_w -name "*counter_collection.csv" | head -1) 3 > $O/pmc_hbm_spconv.json
