@@ -261,11 +261,12 @@ class GradReducer:
 
     def _on_bucket_tail(self, i):
         """Bucket i is complete on the host side: mark it (events on the accumulating streams) and launch the buckets BEFORE it.
-        One bucket of delay on purpose.  The exchange stream's wait for a bucket's events is a barrier in a hardware queue; with four
-        hardware queues for six HIP streams it shares that queue with a compute stream (measured: the exchange stream and the image
-        branch's), and while the barrier is pending -- the host issues the backward several milliseconds ahead of the GPU -- that
-        stream's kernels queue up behind it: +2.5 ms per step on one GPU with no byte moved.  Waiting for the PREVIOUS bucket's
-        events, which are (nearly) reached by the time the next tail arrives, costs +0.6 ms (tools/probes/reducer_ab6.sh)."""
+        One bucket of delay on purpose.  The host issues the backward several milliseconds ahead of the GPU, so a stream-side wait
+        enqueued at a bucket's own tail stays pending for that long, and pending waits are expensive on this stack: +2.5 ms per step
+        on one GPU with no byte moved, all of it gone when the waits are removed (why is not fully established: the exchange stream
+        shares the image branch's hardware queue -- four queues for six streams --, yet the exchange on the default stream costs the
+        same).  Waiting for the PREVIOUS bucket's events, which are (nearly) reached by the time the next
+        tail arrives, costs +0.5-0.8 ms (tools/probes/reducer_ab6.sh)."""
         t0 = time.perf_counter()
         b = self.buckets[i]
         b.tail_seen = True
