@@ -354,7 +354,7 @@ def main():
     model = model.to(device).train()
     if args.bf16_forward:
         model.image_backbone.backbone.set_bf16(True)
-    reducer = GradReducer(model, force_collectives=force_coll) if (world > 1 or force_coll) else None
+    reducer = GradReducer(model, bucket_mb=float(os.environ.get("FTX_BUCKET_MB", "128")), force_collectives=force_coll) if (world > 1 or force_coll) else None
     if os.environ.get("FTX_NO_REDUCER") == "1" and world == 1:
         reducer = None      # measurement aid: the process group exists, the step runs without the reducer
     step = TrainStep(cfg, model, metrics=(m2d, m3d), grad_reducer=reducer)
